@@ -1,0 +1,89 @@
+"""ctypes binding of librs_hip.so, the C-ABI boundary of the hot path.
+
+The library is the product: if it is missing or a symbol cannot be resolved this module raises.
+There is no CPU or eager-PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librs_hip.so")
+
+c_i64p = C.c_void_p
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+I = C.c_int
+F = C.c_float
+L = C.c_longlong
+
+# name -> argtypes (every entry point returns int, except where noted below)
+_SIGS = {
+    "rs_gather_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
+    "rs_gather_lr_fm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p,
+                            c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
+}
+
+_lib = None
+
+
+class RSError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RSError(f"{LIB_PATH} not found: build it with `python -m recommendsystem_amd.build` "
+                      "(there is no fallback path)")
+    h = C.CDLL(LIB_PATH)
+    h.rs_version.restype = I
+    h.rs_version.argtypes = []
+    h.rs_last_error_string.restype = C.c_char_p
+    h.rs_last_error_string.argtypes = []
+    h.rs_device_cu_count.restype = I
+    h.rs_device_cu_count.argtypes = []
+    for name, args in _SIGS.items():
+        fn = getattr(h, name)          # AttributeError if the symbol is missing: loud by design
+        fn.restype = I
+        fn.argtypes = args
+    _lib = h
+    return h
+
+
+def exported_symbols():
+    return ["rs_version", "rs_last_error_string", "rs_device_cu_count", *_SIGS.keys()]
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RSError(f"{what} failed (code {rc}): {lib().rs_last_error_string().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RSError("recommendsystem_amd runs on MI355X only: got a CPU tensor "
+                          "(the package has no CPU fallback)")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)
