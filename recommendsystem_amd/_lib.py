@@ -22,10 +22,49 @@ F = C.c_float
 L = C.c_longlong
 
 # name -> argtypes (every entry point returns int, except where noted below)
+SZ = C.c_size_t
 _SIGS = {
+    # gather.hip
     "rs_gather_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
     "rs_gather_lr_fm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p,
                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
+    # gemm.hip
+    "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
+                    I, I, c_f32p, SZ, c_stream],
+    "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, SZ, c_stream],
+    # sparse.hip
+    "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
+    "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
+                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_sparse_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                         c_f32p, c_f32p, c_stream],
+    "rs_sparse_scatter_dense": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_dense_update": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
+    "rs_sumsq_partials": [c_f32p, L, c_f32p, I, c_stream],
+    "rs_clip_coef": [c_f32p, I, F, c_f32p, c_stream],
+    "rs_opt_prepare": [c_i64p, c_f32p, c_stream],
+    # elementwise.hip
+    "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F, c_stream],
+    "rs_act_fwd": [c_f32p, c_f32p, L, I, c_f32p, c_stream],
+    "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
+    "rs_bn_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, I, F, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_bn_bwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, F, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_ln_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_ln_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_add_f32": [c_f32p, c_f32p, c_f32p, L, c_stream],
+}
+# entry points that do not follow the "returns int status" convention: name -> (restype, argtypes)
+_PLAIN = {
+    "rs_version": (I, []),
+    "rs_last_error_string": (C.c_char_p, []),
+    "rs_device_cu_count": (I, []),
+    "rs_gemm_workspace_bytes": (SZ, [I, I, I]),
+    "rs_gemm_plan": (I, [I, I, I, I, C.POINTER(I)]),
+    "rs_colsum_workspace_bytes": (SZ, [I, I]),
+    "rs_sort_plan_ints": (SZ, [I, I]),
+    "rs_sort_max_entries": (I, []),
+    "rs_sparse_bwd_num_partials": (I, [I, I, I]),
+    "rs_act_bwd_num_partials": (I, [L]),
 }
 
 _lib = None
@@ -44,12 +83,10 @@ def lib():
         raise RSError(f"{LIB_PATH} not found: build it with `python -m recommendsystem_amd.build` "
                       "(there is no fallback path)")
     h = C.CDLL(LIB_PATH)
-    h.rs_version.restype = I
-    h.rs_version.argtypes = []
-    h.rs_last_error_string.restype = C.c_char_p
-    h.rs_last_error_string.argtypes = []
-    h.rs_device_cu_count.restype = I
-    h.rs_device_cu_count.argtypes = []
+    for name, (res, args) in _PLAIN.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
     for name, args in _SIGS.items():
         fn = getattr(h, name)          # AttributeError if the symbol is missing: loud by design
         fn.restype = I
@@ -59,7 +96,7 @@ def lib():
 
 
 def exported_symbols():
-    return ["rs_version", "rs_last_error_string", "rs_device_cu_count", *_SIGS.keys()]
+    return [*_PLAIN.keys(), *_SIGS.keys()]
 
 
 def check(rc: int, what: str):

@@ -1,0 +1,329 @@
+// Small fused elementwise / reduction kernels around the GEMMs: loss head, normalisation layers.
+#include "common.h"
+
+namespace {
+
+// logit = z0 + z1 + z2 (null parts skipped); p = sigmoid(logit);
+// loss = mean(-(y*max(log p,-100) + (1-y)*max(log1p(-p),-100)))    [F.binary_cross_entropy,
+// model/utils/BaseModel.py:75,145 applied to sigmoid outputs as model/LR/LR.py:32 does]
+// dz = dloss/dlogit following autograd's two steps (BCE backward then sigmoid backward).
+__global__ __launch_bounds__(1024) void bce_head_kernel(const float* __restrict__ z0, const float* __restrict__ z1,
+                                                        const float* __restrict__ z2, const float* __restrict__ yf,
+                                                        const int64_t* __restrict__ yi, int B,
+                                                        float* __restrict__ logit_out, float* __restrict__ prob_out,
+                                                        float* __restrict__ loss_out, float* __restrict__ dz_out,
+                                                        float grad_scale) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        float z = z0[b];
+        if (z1) z += z1[b];
+        if (z2) z += z2[b];
+        const float y = yf ? yf[b] : (float)yi[b];
+        const float p = 1.f / (1.f + expf(-z));
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+        s += -(y * lp + (1.f - y) * l1p);
+        if (logit_out) logit_out[b] = z;
+        if (prob_out) prob_out[b] = p;
+        if (dz_out) {
+            const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * invB * grad_scale;
+            dz_out[b] = gp * ((1.f - p) * p);
+        }
+    }
+    const float tot = rs_block_sum<1024>(s, red);
+    if (threadIdx.x == 0 && loss_out) loss_out[0] = tot * invB;
+}
+
+// dst[b] = act(z[b])-style pointwise helpers on vectors -------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, long long n,
+                                                      int act, const float* __restrict__ slope) {
+    const float sl = slope ? slope[0] : 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) h[i] = rs_act(act, z[i], sl);
+}
+
+// dz = dh * act'(z);  for PReLU also the slope gradient partials: sum over z<=0 of dh*z
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z,
+                                                      const float* __restrict__ h, float* __restrict__ dz, long long n,
+                                                      int act, const float* __restrict__ slope,
+                                                      float* __restrict__ dslope_partials) {
+    __shared__ float red[4];
+    const float sl = slope ? slope[0] : 0.f;
+    float ds = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float zz = z ? z[i] : h[i], hh = h ? h[i] : 0.f, g = dh[i];
+        dz[i] = g * rs_act_grad(act, zz, hh, sl);
+        if (act == RS_ACT_PRELU && zz <= 0.f) ds += g * zz;
+    }
+    if (dslope_partials) {
+        const float tot = rs_block_sum<256>(ds, red);
+        if (threadIdx.x == 0) dslope_partials[blockIdx.x] = tot;
+    }
+}
+
+// ---- BatchNorm1d (training: batch statistics; eval: running statistics) ---------------------
+// One workgroup per 32 features; 8 row-lanes x 32 feature-lanes; two passes (mean, then centred
+// variance) for the accuracy of torch's batch_norm.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int M, int N,
+                                                       float* __restrict__ mean, float* __restrict__ var_biased) {
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (n < N) for (int m = r; m < M; m += 8) s += z[(long long)m * N + n];
+    part[r][c] = s;
+    __syncthreads();
+    float mu = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mu += part[i][c];
+    mu /= (float)M;
+    __syncthreads();
+    float q = 0.f;
+    if (n < N) for (int m = r; m < M; m += 8) { const float dlt = z[(long long)m * N + n] - mu; q += dlt * dlt; }
+    part[r][c] = q;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += part[i][c];
+        mean[n] = mu;
+        var_biased[n] = v / (float)M;
+    }
+}
+
+// h = act(gamma * (z - mean) * rsqrt(var + eps) + beta); optionally updates running stats
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int M, int N,
+                                                       const float* __restrict__ mean, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int act, float* __restrict__ xhat,
+                                                       float* __restrict__ h) {
+    const long long total = (long long)M * N;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i % N);
+        const float xh = (z[i] - mean[n]) * (1.f / sqrtf(var[n] + eps));
+        if (xhat) xhat[i] = xh;
+        h[i] = rs_act(act, gamma[n] * xh + beta[n], 0.f);
+    }
+}
+
+__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var_biased, int M, int N,
+                                  float momentum, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+        const float unb = M > 1 ? var_biased[n] * ((float)M / (float)(M - 1)) : var_biased[n];
+        running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mean[n];
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * unb;
+    }
+}
+
+// BatchNorm backward (training).  dy = dh * act'(...) is formed on the fly from h.
+//   dbeta = sum dy, dgamma = sum dy*xhat, dz = gamma*rstd*(dy - dbeta/M - xhat*dgamma/M)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                            const float* __restrict__ xhat, int M, int N, int act,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float p1[8][33], p2[8][33];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float sb = 0.f, sg = 0.f;
+    if (n < N)
+        for (int m = r; m < M; m += 8) {
+            const long long i = (long long)m * N + n;
+            const float hh = h[i];
+            const float dy = dh[i] * rs_act_grad(act, hh, hh, 0.f);   // relu/leaky: sign(h)=sign(z); tanh: from h
+            sb += dy; sg += dy * xhat[i];
+        }
+    p1[r][c] = sb; p2[r][c] = sg;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float b = 0.f, g = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { b += p1[i][c]; g += p2[i][c]; }
+        dbeta[n] = b; dgamma[n] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                           const float* __restrict__ xhat, int M, int N, int act,
+                                                           const float* __restrict__ gamma, const float* __restrict__ var,
+                                                           float eps, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float* __restrict__ dz) {
+    const long long total = (long long)M * N;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float invM = 1.f / (float)M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i % N);
+        const float hh = h[i];
+        const float dy = dh[i] * rs_act_grad(act, hh, hh, 0.f);
+        const float rstd = 1.f / sqrtf(var[n] + eps);
+        dz[i] = gamma[n] * rstd * (dy - dbeta[n] * invM - xhat[i] * dgamma[n] * invM);
+    }
+}
+
+// ---- LayerNorm over the feature dimension: one wave per row ---------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ z, int M, int N,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, int act, float* __restrict__ xhat,
+                                                     float* __restrict__ rstd_out, float* __restrict__ h) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* zr = z + (long long)m * N;
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += zr[n];
+    const float mu = rs_wave_sum(s) / (float)N;
+    float q = 0.f;
+    for (int n = lane; n < N; n += 64) { const float dlt = zr[n] - mu; q += dlt * dlt; }
+    const float rstd = 1.f / sqrtf(rs_wave_sum(q) / (float)N + eps);
+    if (lane == 0) rstd_out[m] = rstd;
+    for (int n = lane; n < N; n += 64) {
+        const float xh = (zr[n] - mu) * rstd;
+        xhat[(long long)m * N + n] = xh;
+        h[(long long)m * N + n] = rs_act(act, gamma[n] * xh + beta[n], 0.f);
+    }
+}
+
+// dz = rstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dy*gamma;  dy = dh*act'(h)
+// also writes dy (into dy_out) so that dgamma/dbeta column sums can run as a second pass.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                     const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int M, int N, int act,
+                                                     float* __restrict__ dz, float* __restrict__ dy_out,
+                                                     float* __restrict__ dyxhat_out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const long long base = (long long)m * N;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float hh = h[base + n];
+        const float dy = dh[base + n] * rs_act_grad(act, hh, hh, 0.f);
+        const float g = dy * gamma[n];
+        s1 += g; s2 += g * xhat[base + n];
+        dy_out[base + n] = dy;
+        dyxhat_out[base + n] = dy * xhat[base + n];
+    }
+    s1 = rs_wave_sum(s1) / (float)N;
+    s2 = rs_wave_sum(s2) / (float)N;
+    const float r = rstd[m];
+    for (int n = lane; n < N; n += 64) {
+        const float g = dy_out[base + n] * gamma[n];
+        dz[base + n] = r * (g - s1 - xhat[base + n] * s2);
+    }
+}
+
+// y = a + b (residual add), flat
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
+}
+
+int flat_blocks(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+// Loss head of the training step; any of logit_out/prob_out/loss_out/dz_out may be null.
+// Labels come either as float (labels_f32) or int64 (labels_i64); exactly one must be non-null.
+int rs_bce_head(const float* z0, const float* z1, const float* z2, const float* labels_f32,
+                const int64_t* labels_i64, int B, float* logit_out, float* prob_out, float* loss_out,
+                float* dz_out, float grad_scale, hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && z0, "rs_bce_head: empty batch or null logits");
+    RS_CHECK_ARG((labels_f32 != nullptr) != (labels_i64 != nullptr), "rs_bce_head: pass exactly one label array");
+    hipLaunchKernelGGL(bce_head_kernel, dim3(1), dim3(1024), 0, stream, z0, z1, z2, labels_f32, labels_i64, B,
+                       logit_out, prob_out, loss_out, dz_out, grad_scale);
+    RS_CHECK_LAUNCH("rs_bce_head");
+    return RS_OK;
+}
+
+int rs_act_fwd(const float* z, float* h, long long n, int act, const float* slope, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && (n == 0 || (z && h)), "rs_act_fwd: bad arguments");
+    RS_CHECK_ARG(act != RS_ACT_PRELU || slope, "rs_act_fwd: PReLU needs its slope");
+    if (n == 0) return RS_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(flat_blocks(n)), dim3(256), 0, stream, z, h, n, act, slope);
+    RS_CHECK_LAUNCH("rs_act_fwd");
+    return RS_OK;
+}
+
+int rs_act_bwd_num_partials(long long n) { return flat_blocks(n); }
+
+// dz = dh * act'(z).  z may be null for activations whose derivative follows from h.
+// dslope_partials (PReLU only): rs_act_bwd_num_partials(n) floats, summed by the caller.
+int rs_act_bwd(const float* dh, const float* z, const float* h, float* dz, long long n, int act, const float* slope,
+               float* dslope_partials, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && (n == 0 || (dh && dz && (z || h))), "rs_act_bwd: bad arguments");
+    RS_CHECK_ARG(act != RS_ACT_PRELU || (slope && z), "rs_act_bwd: PReLU needs slope and z");
+    if (n == 0) return RS_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(flat_blocks(n)), dim3(256), 0, stream, dh, z, h, dz, n, act, slope,
+                       dslope_partials);
+    RS_CHECK_LAUNCH("rs_act_bwd");
+    return RS_OK;
+}
+
+// BatchNorm1d forward over z [M, N] (model/utils/Layers.py:27,44 in train mode when training != 0).
+// training: computes batch mean / biased var into mean,var and updates running stats (momentum 0.1
+// semantics of torch) when running_* are given; eval: uses running stats passed as mean,var.
+int rs_bn_fwd(const float* z, int M, int N, const float* gamma, const float* beta, float eps, int act, int training,
+              float momentum, float* mean, float* var, float* running_mean, float* running_var, float* xhat,
+              float* h, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && z && gamma && beta && mean && var && h, "rs_bn_fwd: bad arguments");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_bn_fwd: activation %d not fusable", act);
+    if (training) {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(rs_cdiv(N, 32)), dim3(256), 0, stream, z, M, N, mean, var);
+        if (running_mean && running_var)
+            hipLaunchKernelGGL(bn_running_kernel, dim3(rs_cdiv(N, 256)), dim3(256), 0, stream, mean, var, M, N, momentum,
+                               running_mean, running_var);
+    }
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(flat_blocks((long long)M * N)), dim3(256), 0, stream, z, M, N, mean, var,
+                       gamma, beta, eps, act, xhat, h);
+    RS_CHECK_LAUNCH("rs_bn_fwd");
+    return RS_OK;
+}
+
+int rs_bn_bwd(const float* dh, const float* h, const float* xhat, int M, int N, int act, const float* gamma,
+              const float* var, float eps, float* dgamma, float* dbeta, float* dz, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && dh && h && xhat && gamma && var && dgamma && dbeta && dz, "rs_bn_bwd: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rs_cdiv(N, 32)), dim3(256), 0, stream, dh, h, xhat, M, N, act, dgamma,
+                       dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_blocks((long long)M * N)), dim3(256), 0, stream, dh, h, xhat, M, N,
+                       act, gamma, var, eps, dgamma, dbeta, dz);
+    RS_CHECK_LAUNCH("rs_bn_bwd");
+    return RS_OK;
+}
+
+int rs_ln_fwd(const float* z, int M, int N, const float* gamma, const float* beta, float eps, int act, float* xhat,
+              float* rstd, float* h, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && z && gamma && beta && xhat && rstd && h, "rs_ln_fwd: bad arguments");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_ln_fwd: activation %d not fusable", act);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(rs_cdiv(M, 4)), dim3(256), 0, stream, z, M, N, gamma, beta, eps, act, xhat,
+                       rstd, h);
+    RS_CHECK_LAUNCH("rs_ln_fwd");
+    return RS_OK;
+}
+
+// LayerNorm backward: dz, plus dy and dy*xhat (both [M, N]) whose column sums are dbeta / dgamma.
+int rs_ln_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gamma, int M, int N,
+              int act, float* dz, float* dy, float* dyxhat, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && dh && h && xhat && rstd && gamma && dz && dy && dyxhat, "rs_ln_bwd: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(rs_cdiv(M, 4)), dim3(256), 0, stream, dh, h, xhat, rstd, gamma, M, N, act, dz,
+                       dy, dyxhat);
+    RS_CHECK_LAUNCH("rs_ln_bwd");
+    return RS_OK;
+}
+
+int rs_add_f32(const float* a, const float* b, float* y, long long n, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && (n == 0 || (a && b && y)), "rs_add_f32: bad arguments");
+    if (n == 0) return RS_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(flat_blocks(n)), dim3(256), 0, stream, a, b, y, n);
+    RS_CHECK_LAUNCH("rs_add_f32");
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -170,6 +170,7 @@ int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int
                         const float* table, const float* table1, const float* bias,
                         float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out,
                         int B, int F, int d, int* err_flag, hipStream_t stream) {
+    if (B == 0) return RS_OK;
     RS_CHECK_ARG(idx && row_offset && vocab, "rs_gather_lr_fm_fwd: null index arguments");
     RS_CHECK_ARG(B >= 0 && F > 0 && d > 0, "rs_gather_lr_fm_fwd: bad sizes B=%d F=%d d=%d", B, F, d);
     RS_CHECK_ARG(table || table1, "rs_gather_lr_fm_fwd: both tables are null");

@@ -1,0 +1,365 @@
+// K2e: fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bit-for-bit an fmaf chain in k order), with the MLP epilogues fused.
+//
+//   C[m, n] = epi( sum_k A(m, k) * B(k, n) )
+//
+// Operand storage (both fp32, row strides in elements):
+//   A_MC = 0 : A(m, k) = A[m*lda + k]   (k contiguous; activations [M, K])
+//   A_MC = 1 : A(m, k) = A[k*lda + m]   (m contiguous; used for dW = dZ^T X)
+//   B_NC = 0 : B(k, n) = B[n*ldb + k]   (k contiguous; nn.Linear weight [out, in])
+//   B_NC = 1 : B(k, n) = B[k*ldb + n]   (n contiguous; used for dX = dZ W and dW = dZ^T X)
+//
+// The three products of an MLP layer (model/utils/Layers.py:42 forward; its autograd backward):
+//   forward  H  = act(X W^T + b)            A_MC=0 B_NC=0, epilogue bias + activation
+//   dX/dZ'   dZ'= (dZ W) * act'(H_prev)     A_MC=0 B_NC=1, epilogue multiplies by act' of the
+//                                           previous layer's output
+//   dW       dW = dZ^T X                    A_MC=1 B_NC=1, split over the batch (K) dimension,
+//                                           partial slabs summed in fixed order (deterministic)
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid, block tile BM x BN (64 or 128 each), BK = 32.
+// Both operand tiles are staged global -> registers -> LDS in k-major form S[k][m] so that an
+// MFMA operand is one conflict-free ds_read_b32 per lane (lanes run along m, the lane half picks
+// k); the next tile's global loads are issued before the MFMAs of the current tile and written to
+// the other LDS buffer after them (one barrier per k-tile).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 32;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;      // [N] or null
+    const float* mulsrc;    // [M, ldm] or null: C *= act_grad(mul_act, h = mulsrc[m, n])
+    int M, N, K, lda, ldb, ldc, ldm;
+    int act, mul_act;
+    int kchunk;             // k range per blockIdx.z (multiple of BK)
+    int splitk;
+    float* ws;              // [splitk, M, N] partial slabs when splitk > 1
+};
+
+__device__ __forceinline__ float act_grad_from_h(int act, float h) {
+    switch (act) {
+        case RS_ACT_RELU: return h > 0.f ? 1.f : 0.f;
+        case RS_ACT_TANH: return 1.f - h * h;
+        case RS_ACT_LEAKYRELU: return h > 0.f ? 1.f : 0.01f;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int n) {
+    if (g.bias) v += g.bias[n];
+    v = rs_act(g.act, v, 0.f);
+    if (g.mulsrc) v *= act_grad_from_h(g.mul_act, g.mulsrc[(long long)m * g.ldm + n]);
+    return v;
+}
+
+// ---- tile staging -----------------------------------------------------------------------------
+// R = rows of the tile along the non-k dimension (BM or BN).  MC: that dimension is contiguous
+// in global memory.  V: 16-byte loads are legal (alignment checked on the host).
+template <int R, bool MC, bool V> struct Stage {
+    static constexpr int LD = MC ? R + 4 : R + 1;
+    static constexpr int NV = V ? R / 32 : R / 8;       // registers (float4 or float) per thread
+    using reg_t = typename std::conditional<V, float4, float>::type;
+
+    __device__ static __forceinline__ void load(reg_t (&r)[NV], const float* __restrict__ P, int ld, int rows,
+                                                int row0, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (V && !MC) {          // 8 lanes cover 32 consecutive k of one row
+                const int row = row0 + (tid >> 3) + i * 32, k = k0 + (tid & 7) * 4;
+                r[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4*>(P + (long long)row * ld + k)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if constexpr (V && MC) {    // consecutive lanes along the contiguous dimension
+                const int e = tid + i * 256, k = k0 + e / (R / 4), row = row0 + (e % (R / 4)) * 4;
+                r[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4*>(P + (long long)k * ld + row)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if constexpr (!V && !MC) {
+                const int e = tid + i * 256, k = k0 + (e & 31), row = row0 + (e >> 5);
+                r[i] = (row < rows && k < kend) ? P[(long long)row * ld + k] : 0.f;
+            } else {
+                const int e = tid + i * 256, k = k0 + e / R, row = row0 + (e % R);
+                r[i] = (row < rows && k < kend) ? P[(long long)k * ld + row] : 0.f;
+            }
+        }
+    }
+    __device__ static __forceinline__ void store(const reg_t (&r)[NV], float* S, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if constexpr (V && !MC) {
+                const int row = (tid >> 3) + i * 32, k = (tid & 7) * 4;
+                S[(k + 0) * LD + row] = r[i].x;
+                S[(k + 1) * LD + row] = r[i].y;
+                S[(k + 2) * LD + row] = r[i].z;
+                S[(k + 3) * LD + row] = r[i].w;
+            } else if constexpr (V && MC) {
+                const int e = tid + i * 256, k = e / (R / 4), row = (e % (R / 4)) * 4;
+                *reinterpret_cast<float4*>(S + k * LD + row) = r[i];
+            } else if constexpr (!V && !MC) {
+                const int e = tid + i * 256;
+                S[(e & 31) * LD + (e >> 5)] = r[i];
+            } else {
+                const int e = tid + i * 256;
+                S[(e / R) * LD + (e % R)] = r[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool A_MC, bool B_NC, bool VA, bool VB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    using SA = Stage<BM, A_MC, VA>;
+    using SB = Stage<BN, B_NC, VB>;
+    constexpr int A_STAGE = BK * SA::LD, B_STAGE = BK * SB::LD;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typename SA::reg_t ra[SA::NV];
+    typename SB::reg_t rb[SB::NV];
+    if (nk > 0) {
+        SA::load(ra, g.A, g.lda, g.M, m0, kbeg, kend, tid);
+        SB::load(rb, g.B, g.ldb, g.N, n0, kbeg, kend, tid);
+        SA::store(ra, As, tid);
+        SB::store(rb, Bs, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            SA::load(ra, g.A, g.lda, g.M, m0, kbeg + (kt + 1) * BK, kend, tid);
+            SB::load(rb, g.B, g.ldb, g.N, n0, kbeg + (kt + 1) * BK, kend, tid);
+        }
+        const float* as = As + cur * A_STAGE + wm0 + li;
+        const float* bs = Bs + cur * B_STAGE + wn0 + li;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[(kk * 2 + lh) * SA::LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[(kk * 2 + lh) * SB::LD + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            SA::store(ra, As + (cur ^ 1) * A_STAGE, tid);
+            SB::store(rb, Bs + (cur ^ 1) * B_STAGE, tid);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool partial = g.splitk > 1;
+    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = partial ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (!partial) v = epilogue(g, v, m, n);
+                    out[(long long)m * ldo + n] = v;
+                }
+            }
+        }
+}
+
+// Sum the split-K slabs in slab order and apply the epilogue.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+    const long long total = (long long)g.M * g.N;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        float v = 0.f;
+        for (int z = 0; z < g.splitk; ++z) v += g.ws[z * total + e];
+        const int m = (int)(e / g.N), n = (int)(e % g.N);
+        g.C[(long long)m * g.ldc + n] = epilogue(g, v, m, n);
+    }
+}
+
+template <int BM, int BN, bool A_MC, bool B_NC, bool VA, bool VB>
+int launch(const GemmArgs& g, hipStream_t stream) {
+    using SA = Stage<BM, A_MC, VA>;
+    using SB = Stage<BN, B_NC, VB>;
+    constexpr size_t smem = (size_t)2 * BK * (SA::LD + SB::LD) * sizeof(float);
+    auto kern = gemm_f32_kernel<BM, BN, A_MC, B_NC, VA, VB>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) {
+            rs_set_error("rs_gemm_f32: cannot raise dynamic LDS limit to %zu", smem);
+            return RS_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(rs_cdiv(g.N, BN), rs_cdiv(g.M, BM), g.splitk), block(256);
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, g);
+    RS_CHECK_LAUNCH("rs_gemm_f32");
+    if (g.splitk > 1) {
+        const long long total = (long long)g.M * g.N;
+        int blocks = (int)min((long long)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
+        RS_CHECK_LAUNCH("rs_gemm_f32(split-k reduce)");
+    }
+    return RS_OK;
+}
+
+template <bool A_MC, bool B_NC>
+int dispatch(const GemmArgs& g, bool va, bool vb, int tile, hipStream_t s) {
+    if (va && vb) {
+        switch (tile) {
+            case 0: return launch<128, 128, A_MC, B_NC, true, true>(g, s);
+            case 1: return launch<128, 64, A_MC, B_NC, true, true>(g, s);
+            case 2: return launch<64, 128, A_MC, B_NC, true, true>(g, s);
+            default: return launch<64, 64, A_MC, B_NC, true, true>(g, s);
+        }
+    }
+    if (va) return launch<64, 64, A_MC, B_NC, true, false>(g, s);
+    if (vb) return launch<64, 64, A_MC, B_NC, false, true>(g, s);
+    return launch<64, 64, A_MC, B_NC, false, false>(g, s);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// column sums: out[n] = sum_m X[m, n].  Stage 1: one workgroup per (64 columns, 256 rows) writes a
+// partial row; stage 2 adds the partial rows in order.  Fixed summation order.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, int M, int N, int ld,
+                                                            float* __restrict__ part_out) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int mbeg = blockIdx.y * CS_ROWS, mend = min(M, mbeg + CS_ROWS);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mbeg + w; m < mend; m += 4) s += X[(long long)m * ld + n];
+    part[w][c] = s;
+    __syncthreads();
+    if (w == 0 && n < N) part_out[(long long)blockIdx.y * N + n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int chunks, int N,
+                                                            float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long long)c * N + n];
+    out[n] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rs_gemm_workspace_bytes(int M, int N, int splitk) {
+    return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+}
+
+// Tile/split choice for a problem on a device with `cus` compute units.
+// Returns tile code (0:128x128 1:128x64 2:64x128 3:64x64) and writes the split count.
+int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out) {
+    const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
+    int best = 3;
+    // largest tile that still yields >= 2 blocks per CU; else the one with most blocks
+    for (int t = 0; t < 4; ++t) {
+        long long blocks = (long long)rs_cdiv(M, bm[t]) * rs_cdiv(N, bn[t]);
+        if (blocks >= 2LL * cus) { best = t; break; }
+    }
+    long long blocks = (long long)rs_cdiv(M, bm[best]) * rs_cdiv(N, bn[best]);
+    int sk = 1;
+    if (blocks < cus && K >= 8 * BK) {
+        sk = (int)((2LL * cus + blocks - 1) / blocks);
+        const int maxsk = K / (4 * BK);
+        if (sk > maxsk) sk = maxsk;
+        if (sk > 16) sk = 16;
+        if (sk < 1) sk = 1;
+    }
+    *splitk_out = sk;
+    return best;
+}
+
+// C = epi(op(A) op(B)); see the header of this file for operand conventions.
+// tile < 0 and splitk <= 0 let the library choose.  workspace is needed only when the resolved
+// split count is > 1 (query the size with rs_gemm_workspace_bytes using the same splitk, or pass
+// a buffer sized for splitk = 16).
+int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
+                int tile, int splitk, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "rs_gemm_f32: negative size");
+    if (M == 0 || N == 0) return RS_OK;
+    RS_CHECK_ARG(A && B && C, "rs_gemm_f32: null operand");
+    RS_CHECK_ARG(!(a_mc && !b_nc), "rs_gemm_f32: layout (A m-contiguous, B k-contiguous) is not provided");
+    RS_CHECK_ARG(lda >= (a_mc ? M : K) && ldb >= (b_nc ? N : K) && ldc >= N, "rs_gemm_f32: bad leading dims");
+    RS_CHECK_ARG(!mulsrc || ldm >= N, "rs_gemm_f32: bad ldm");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_gemm_f32: activation %d not fusable", act);
+    int cus = 256;
+    if (tile < 0 || splitk <= 0) {
+        int sk = 1;
+        int t = rs_gemm_plan(M, N, K, cus, &sk);
+        if (tile < 0) tile = t;
+        if (splitk <= 0) splitk = sk;
+    }
+    if (splitk > 1) {
+        int maxsk = rs_cdiv(K, BK);
+        if (splitk > maxsk) splitk = maxsk > 0 ? maxsk : 1;
+    }
+    if (splitk > 1)
+        RS_CHECK_ARG(workspace && workspace_bytes >= rs_gemm_workspace_bytes(M, N, splitk),
+                     "rs_gemm_f32: workspace too small for splitk=%d (%zu bytes given)", splitk, workspace_bytes);
+    GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace};
+    g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
+    if (g.kchunk == 0) g.kchunk = BK;
+    const bool va = aligned16(A) && lda % 4 == 0 && (a_mc ? M % 4 == 0 : K % 4 == 0);
+    const bool vb = aligned16(B) && ldb % 4 == 0 && (b_nc ? N % 4 == 0 : K % 4 == 0);
+    if (!a_mc && !b_nc) return dispatch<false, false>(g, va, vb, tile, stream);
+    if (!a_mc && b_nc) return dispatch<false, true>(g, va, vb, tile, stream);
+    return dispatch<true, true>(g, va, vb, tile, stream);
+}
+
+size_t rs_colsum_workspace_bytes(int M, int N) { return (size_t)rs_cdiv(M, CS_ROWS) * N * sizeof(float); }
+
+// out[n] = sum_m X[m, n]  (bias gradient of nn.Linear, model/utils/Layers.py:42; also the
+// dgamma/dbeta sums of LayerNorm).  workspace: rs_colsum_workspace_bytes(M, N).
+int rs_colsum_f32(const float* X, int M, int N, int ld, float* out, float* workspace, size_t workspace_bytes,
+                  hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "rs_colsum_f32: bad sizes");
+    if (N == 0) return RS_OK;
+    RS_CHECK_ARG(out, "rs_colsum_f32: null output");
+    if (M == 0) { hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream); return RS_OK; }
+    RS_CHECK_ARG(X, "rs_colsum_f32: null input");
+    RS_CHECK_ARG(workspace && workspace_bytes >= rs_colsum_workspace_bytes(M, N), "rs_colsum_f32: workspace too small");
+    const int chunks = rs_cdiv(M, CS_ROWS);
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(rs_cdiv(N, 64), chunks), dim3(256), 0, stream, X, M, N, ld, workspace);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 256)), dim3(256), 0, stream, workspace, chunks, N, out);
+    RS_CHECK_LAUNCH("rs_colsum_f32");
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,597 @@
+// K3: deterministic sparse embedding backward for gfx950.
+//
+// The reference trains dense nn.Embedding tables: autograd writes a full (V, d) gradient per
+// table in which only the rows named by the batch are non-zero (row 0 = padding_idx never
+// receives gradient: model/utils/Layers.py:132), then clips the global norm and steps a dense
+// optimizer (model/utils/BaseModel.py:141-150).  Here the same row gradients are produced
+// without ever touching the untouched rows:
+//
+//   1. field_sort_kernel    one workgroup per field: stable LSD radix sort (1 bit per pass) of the
+//                           field's indices entirely in LDS, then run-length segmentation: one
+//                           "segment" per distinct row, cut into "chunks" of at most L entries.
+//   2. chunk_reduce_kernel  a lane group per chunk sums its gradient rows in ascending sample
+//                           order (sequential adds: fixed order, no atomics).
+//   3. segment_finalize     a lane group per segment adds its chunk sums in chunk order, writes the
+//                           row gradient, and accumulates ||g||^2 partials per workgroup.
+//   4. sparse_update        SGD / Adam / AdamW / Adagrad on the touched rows only, scaled by the
+//                           global clip coefficient (a device scalar, so no host round trip).
+//      scatter_rowgrad      alternative consumer: expand into a dense (R, d) gradient for callers
+//                           that keep the reference's dense torch optimizers.
+#include "common.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 1024;
+
+struct SortArgs {
+    const int64_t* keys;      // index storage (int64, as the reference's .long() batches)
+    const int* sub_off;       // [nsrc*F] start of sub-list (s, f) inside keys
+    const int* sub_cnt;       // [nsrc*F] entries in sub-list (s, f)
+    const int* pay_base;      // [nsrc*F] gradient-row index of the first entry of sub-list (s, f)
+    int pay_stride;           // gradient-row index step between consecutive entries
+    int nsrc, F, cap, L;
+    const int64_t* vocab;     // [F]
+    const int64_t* row_offset;// [F]
+    int* sorted_src;          // [F, cap]   gradient-row index of the i-th entry in key order
+    int* chunk_start;         // [F, cap+1] first sorted position of each chunk (+ sentinel)
+    int* seg_row;             // [F, cap]   stacked-table row of each segment
+    int* seg_first_chunk;     // [F, cap+1] first chunk of each segment (+ sentinel)
+    int* counts;              // [F, 4]     n, n_chunk, n_seg, n_padding
+};
+
+// Exclusive scan of one int per thread over the 1024-thread workgroup; *total gets the sum.
+__device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                       // scratch may still be read from a previous call
+    if (lane == 63) scratch[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_THREADS / 64; ++i) {
+        const int s = scratch[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*ITEMS]
+    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32]
+    const int f = blockIdx.x;
+    const int t = threadIdx.x;
+    constexpr int CAPB = SORT_THREADS * ITEMS;
+
+    // ---- load the field's sub-lists into LDS in list order (position = order of arrival) ----
+    int n = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const int cnt = a.sub_cnt[s * a.F + f];
+        const int off = a.sub_off[s * a.F + f];
+        const int pb = a.pay_base[s * a.F + f];
+        const long long V = a.vocab[f];
+        for (int j = t; j < cnt; j += SORT_THREADS) {
+            long long k = a.keys[off + j];
+            if (k < 0 || k >= V) k = 0;    // out-of-range was flagged by the forward; treat as padding
+            buf[n + j] = ((unsigned long long)(unsigned)k << 32) | (unsigned)(pb + j * a.pay_stride);
+        }
+        n += cnt;
+    }
+    for (int j = n + t; j < CAPB; j += SORT_THREADS) buf[j] = ~0ull;   // sentinels sort last
+    __syncthreads();
+
+    unsigned long long it[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
+
+    int nbits = 1;
+    {
+        unsigned long long vmax = (unsigned long long)(a.vocab[f] - 1);
+        while ((vmax >> nbits) != 0 && nbits < 32) ++nbits;
+    }
+    for (int bit = 0; bit < nbits; ++bit) {
+        const int sh = 32 + bit;
+        int zl = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) zl += 1 - (int)((it[j] >> sh) & 1ull);
+        int total_zeros;
+        const int ex = block_excl_scan(zl, scratch, &total_zeros);
+        int z = ex, o = total_zeros + (t * ITEMS - ex);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int b1 = (int)((it[j] >> sh) & 1ull);
+            const int rank = b1 ? o : z;
+            o += b1; z += 1 - b1;
+            buf[rank] = it[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
+        __syncthreads();
+    }
+
+    // ---- segmentation: heads of runs of equal keys, chunk heads every L sorted positions ----
+    int flags[ITEMS];
+    int packed = 0, padl = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = t * ITEMS + j;
+        flags[j] = 0;
+        if (i < n) {
+            const unsigned k = (unsigned)(it[j] >> 32);
+            if (k == 0) { ++padl; }
+            else {
+                const bool head = (i == 0) || ((unsigned)(buf[i - 1] >> 32) != k);
+                const bool chead = head || (i % a.L == 0);
+                flags[j] = (head ? 1 : 0) | (chead ? 2 : 0);
+                packed += (head ? 1 : 0) + (chead ? (1 << 16) : 0);
+            }
+        }
+    }
+    int tot, totpad;
+    int ex = block_excl_scan(packed, scratch, &tot);
+    (void)block_excl_scan(padl, scratch, &totpad);
+    const int n_seg = tot & 0xFFFF, n_chunk = tot >> 16;
+    int seg = (ex & 0xFFFF), chk = (ex >> 16);
+    int* sorted_src = a.sorted_src + (long long)f * a.cap;
+    int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
+    int* seg_row = a.seg_row + (long long)f * a.cap;
+    int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
+    const int roff = (int)a.row_offset[f];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = t * ITEMS + j;
+        if (i < n) {
+            sorted_src[i] = (int)(unsigned)(it[j] & 0xFFFFFFFFull);
+            if (flags[j] & 1) {
+                seg_row[seg] = roff + (int)(unsigned)(it[j] >> 32);
+                seg_first_chunk[seg] = chk;
+                ++seg;
+            }
+            if (flags[j] & 2) { chunk_start[chk] = i; ++chk; }
+        }
+    }
+    if (t == 0) {
+        chunk_start[n_chunk] = n;
+        seg_first_chunk[n_seg] = n_chunk;
+        int* c = a.counts + f * 4;
+        c[0] = n; c[1] = n_chunk; c[2] = n_seg; c[3] = totpad;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const int* sorted_src; const int* chunk_start; const int* seg_row; const int* seg_first_chunk;
+    const int* counts;
+    int F, cap, d, C;            // C lanes per chunk/segment (d/4 or d)
+    // gradient sources
+    const float* gout;           // [*, d] gradient rows, indexed by sorted_src (or null)
+    const float* g1src;          // [*]    1-dim gradient per gradient row (or null)
+    const float* dfm;            // [B]    dL/d(fm logit) per sample (or null): adds dfm*(S - e)
+    const float* S;              // [B, d]
+    const float* emb;            // [B*F, d]
+    const float* dlr;            // [B]    dL/d(lr logit) per sample (or null): 1-dim gradient
+    int Fdiv;                    // sample = gradient-row index / Fdiv (columnar batches)
+    float* chunk_sum;            // [F, cap, d]
+    float* chunk_sum1;           // [F, cap] (or null)
+    float* rowgrad;              // [F, cap, d]
+    float* rowgrad1;             // [F, cap] (or null)
+    float* norm_partials;        // [gridDim.x * gridDim.y] of the finalize launch
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
+    const int f = blockIdx.y;
+    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
+    const int gpb = 256 / a.C;
+    const int c = blockIdx.x * gpb + grp;
+    if (grp >= gpb || c >= a.counts[f * 4 + 1]) return;
+    const int* cs = a.chunk_start + (long long)f * (a.cap + 1);
+    const int* ss = a.sorted_src + (long long)f * a.cap;
+    const int i0 = cs[c], i1 = cs[c + 1];
+    const int d = a.d, co = cc * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    float acc1 = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const int src = ss[i];
+        float g[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+        if (a.gout) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(a.gout + (long long)src * d + co);
+                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+            } else g[0] = a.gout[(long long)src * d + co];
+        }
+        const int b = src / a.Fdiv;
+        if (a.dfm) {
+            const float s = a.dfm[b];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                g[e] += s * (a.S[(long long)b * d + co + e] - a.emb[(long long)src * d + co + e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += g[e];
+        if (cc == 0) {
+            if (a.g1src) acc1 += a.g1src[src];
+            if (a.dlr) acc1 += a.dlr[b];
+        }
+    }
+    float* o = a.chunk_sum + ((long long)f * a.cap + c) * d + co;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = acc[e];
+    if (cc == 0 && a.chunk_sum1) a.chunk_sum1[(long long)f * a.cap + c] = acc1;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
+    const int gpb = 256 / a.C;
+    const int u = blockIdx.x * gpb + grp;
+    float nsq = 0.f;
+    if (grp < gpb && u < a.counts[f * 4 + 2]) {
+        const int* sf = a.seg_first_chunk + (long long)f * (a.cap + 1);
+        const int c0 = sf[u], c1 = sf[u + 1];
+        const int d = a.d, co = cc * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        float acc1 = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            const float* p = a.chunk_sum + ((long long)f * a.cap + c) * d + co;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += p[e];
+            if (cc == 0 && a.chunk_sum1) acc1 += a.chunk_sum1[(long long)f * a.cap + c];
+        }
+        float* o = a.rowgrad + ((long long)f * a.cap + u) * d + co;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { o[e] = acc[e]; nsq += acc[e] * acc[e]; }
+        if (cc == 0 && a.rowgrad1) { a.rowgrad1[(long long)f * a.cap + u] = acc1; nsq += acc1 * acc1; }
+    }
+    const float tot = rs_block_sum<256>(nsq, red);
+    if (threadIdx.x == 0) a.norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+// -------------------------------------------------------------------------------------------
+// hyper[]: 0 lr, 1 beta1, 2 beta2, 3 eps, 4 weight_decay, 5 step_size (= lr / (1-beta1^t)),
+//          6 sqrt(1-beta2^t), 7 reserved.  scal[]: 0 total grad norm, 1 clip coefficient.
+enum { OPT_SGD = 0, OPT_ADAM = 1, OPT_ADAMW = 2, OPT_ADAGRAD = 3 };
+
+__device__ __forceinline__ void opt_update(int opt, const float* __restrict__ hy, float g, float& w, float* m,
+                                           float* v) {
+    const float lr = hy[0];
+    if (opt == OPT_SGD) {
+        w = w - lr * g;
+    } else if (opt == OPT_ADAGRAD) {
+        const float s = *m + g * g;          // state sum lives in the `m` slot
+        *m = s;
+        w = w - lr * (g / (sqrtf(s) + hy[3]));
+    } else {
+        if (opt == OPT_ADAMW) w = w * (1.f - lr * hy[4]);
+        const float b1 = hy[1], b2 = hy[2];
+        const float mm = *m + (g - *m) * (1.f - b1);
+        const float vv = *v * b2 + (1.f - b2) * g * g;
+        *m = mm; *v = vv;
+        const float denom = sqrtf(vv) / hy[6] + hy[3];
+        w = w - hy[5] * (mm / denom);
+    }
+}
+
+struct UpdateArgs {
+    const int* seg_row; const int* counts;
+    const float* rowgrad; const float* rowgrad1;
+    int F, cap, d, C, opt;
+    float* table; float* m; float* v;          // [R, d]
+    float* table1; float* m1; float* v1;       // [R] (or null)
+    const float* hyper; const float* scal;     // device scalars
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sparse_update_kernel(UpdateArgs a) {
+    const int f = blockIdx.y;
+    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
+    const int gpb = 256 / a.C;
+    const int u = blockIdx.x * gpb + grp;
+    if (grp >= gpb || u >= a.counts[f * 4 + 2]) return;
+    const long long row = a.seg_row[(long long)f * a.cap + u];
+    const float coef = a.scal ? a.scal[1] : 1.f;
+    const int d = a.d, co = cc * VEC;
+    if (a.table) {
+        const float* gp = a.rowgrad + ((long long)f * a.cap + u) * d + co;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const long long o = row * d + co + e;
+            float w = a.table[o];
+            opt_update(a.opt, a.hyper, gp[e] * coef, w, a.m ? a.m + o : nullptr, a.v ? a.v + o : nullptr);
+            a.table[o] = w;
+        }
+    }
+    if (cc == 0 && a.table1) {
+        float w = a.table1[row];
+        opt_update(a.opt, a.hyper, a.rowgrad1[(long long)f * a.cap + u] * coef, w, a.m1 ? a.m1 + row : nullptr,
+                   a.v1 ? a.v1 + row : nullptr);
+        a.table1[row] = w;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void scatter_rowgrad_kernel(UpdateArgs a) {
+    // a.table = dense gradient [R, d] (pre-zeroed), a.table1 = dense 1-dim gradient [R]
+    const int f = blockIdx.y;
+    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
+    const int gpb = 256 / a.C;
+    const int u = blockIdx.x * gpb + grp;
+    if (grp >= gpb || u >= a.counts[f * 4 + 2]) return;
+    const long long row = a.seg_row[(long long)f * a.cap + u];
+    const int d = a.d, co = cc * VEC;
+    if (a.table) {
+        const float* gp = a.rowgrad + ((long long)f * a.cap + u) * d + co;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a.table[row * d + co + e] = gp[e];
+    }
+    if (cc == 0 && a.table1) a.table1[row] = a.rowgrad1[(long long)f * a.cap + u];
+}
+
+// dense flat-buffer optimizer step (MLP towers, biases): one launch over all dense parameters
+__global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                           float* m, float* v, long long n, int opt,
+                                                           const float* __restrict__ hyper,
+                                                           const float* __restrict__ scal, float l2) {
+    const float coef = scal ? scal[1] : 1.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float ww = w[i];
+        opt_update(opt, hyper, g[i] * coef, ww, m ? m + i : nullptr, v ? v + i : nullptr);
+        w[i] = ww;
+    }
+}
+
+// sum of squares -> one partial per workgroup (fixed grid => fixed summation order)
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ x, long long n,
+                                                             float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+    const float tot = rs_block_sum<256>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6))   [torch clip_grad_norm_]
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partials, int n, float max_norm,
+                                                        float* __restrict__ scal) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    const float tot = rs_block_sum<256>(s, red);
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(tot);
+        scal[0] = nrm;
+        float c = max_norm / (nrm + 1e-6f);
+        scal[1] = (max_norm > 0.f && c < 1.f) ? c : 1.f;
+    }
+}
+
+// step += 1; bias corrections in double precision as torch computes them on the host
+__global__ void opt_prepare_kernel(long long* step, float* hyper) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long t = *step + 1;
+        *step = t;
+        const double b1 = (double)hyper[1], b2 = (double)hyper[2];
+        const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+        hyper[5] = (float)((double)hyper[0] / bc1);
+        hyper[6] = (float)sqrt(bc2);
+    }
+}
+
+int lanes_for(int d, int* VEC, int* C) {
+    if (d % 4 == 0 && d / 4 <= 256) { *VEC = 4; *C = d / 4; return 0; }
+    if (d <= 256) { *VEC = 1; *C = d; return 0; }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Bytes of int32 scratch per field-sort output set with capacity `cap` entries per field:
+//   sorted_src [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] | seg_first_chunk [F,cap+1] | counts [F,4]
+size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (4 * (size_t)cap + 2 + 4); }
+
+int rs_sort_max_entries(void) { return SORT_THREADS * 16; }
+
+// Per-field stable radix sort + segmentation (see file header).  `plan` is int32 scratch of
+// rs_sort_plan_ints(F, cap) elements laid out as above.
+int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base,
+                       int pay_stride, int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
+                       const int64_t* row_offset, int* plan, hipStream_t stream) {
+    RS_CHECK_ARG(keys && sub_off && sub_cnt && pay_base && vocab && row_offset && plan, "rs_sparse_bwd_sort: null argument");
+    RS_CHECK_ARG(F > 0 && nsrc > 0 && cap > 0 && L > 0, "rs_sparse_bwd_sort: bad sizes");
+    RS_CHECK_ARG(max_entries <= cap, "rs_sparse_bwd_sort: max_entries %d exceeds plan capacity %d", max_entries, cap);
+    RS_CHECK_ARG(max_entries <= SORT_THREADS * 16,
+                 "rs_sparse_bwd_sort: %d entries per field exceed the in-LDS sort limit %d", max_entries,
+                 SORT_THREADS * 16);
+    SortArgs a;
+    a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
+    a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
+    int* p = plan;
+    a.sorted_src = p; p += (size_t)F * cap;
+    a.chunk_start = p; p += (size_t)F * (cap + 1);
+    a.seg_row = p; p += (size_t)F * cap;
+    a.seg_first_chunk = p; p += (size_t)F * (cap + 1);
+    a.counts = p;
+    int items = 1;
+    while (items * SORT_THREADS < max_entries) items <<= 1;
+    if (items < 4) items = 4;
+    const size_t smem = (size_t)SORT_THREADS * items * 8 + 32 * sizeof(int);
+#define RS_SORT_LAUNCH(IT)                                                                          \
+    do {                                                                                            \
+        static bool attr = false;                                                                   \
+        if (!attr) {                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(field_sort_kernel<IT>),           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
+                rs_set_error("rs_sparse_bwd_sort: cannot reserve %zu bytes of LDS", smem);          \
+                return RS_ERR_LAUNCH;                                                               \
+            }                                                                                       \
+            attr = true;                                                                            \
+        }                                                                                           \
+        hipLaunchKernelGGL(field_sort_kernel<IT>, dim3(F), dim3(SORT_THREADS), smem, stream, a);   \
+    } while (0)
+    if (items == 4) RS_SORT_LAUNCH(4);
+    else if (items == 8) RS_SORT_LAUNCH(8);
+    else RS_SORT_LAUNCH(16);
+#undef RS_SORT_LAUNCH
+    RS_CHECK_LAUNCH("rs_sparse_bwd_sort");
+    return RS_OK;
+}
+
+static int fill_reduce(ReduceArgs& a, const int* plan, int F, int cap, int d, int* VEC) {
+    const int* p = plan;
+    a.sorted_src = p; p += (size_t)F * cap;
+    a.chunk_start = p; p += (size_t)F * (cap + 1);
+    a.seg_row = p; p += (size_t)F * cap;
+    a.seg_first_chunk = p; p += (size_t)F * (cap + 1);
+    a.counts = p;
+    a.F = F; a.cap = cap; a.d = d;
+    return lanes_for(d, VEC, &a.C);
+}
+
+// Number of norm partials rs_sparse_bwd_reduce writes.
+int rs_sparse_bwd_num_partials(int F, int cap, int d) {
+    int VEC, C;
+    if (lanes_for(d, &VEC, &C) != 0) return -1;
+    return F * rs_cdiv(cap, 256 / C);
+}
+
+// Segmented reduction of gradient rows into one row gradient per touched table row, plus
+// per-workgroup ||g||^2 partials.  Gradient of entry with gradient-row index r (sample b = r/Fdiv):
+//   g = gout[r, :] (if gout) + dfm[b] * (S[b, :] - emb[r, :]) (if dfm);  1-dim: g1src[r] + dlr[b].
+int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                         const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                         float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1,
+                         float* norm_partials, hipStream_t stream) {
+    RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce: null argument");
+    RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce: dfm needs S and emb");
+    RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce: chunk_sum1/rowgrad1 mismatch");
+    RS_CHECK_ARG(Fdiv > 0, "rs_sparse_bwd_reduce: Fdiv must be positive");
+    ReduceArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_reduce(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_bwd_reduce: unsupported d=%d", d);
+    a.gout = gout; a.g1src = g1src; a.dfm = dfm; a.S = S; a.emb = emb; a.dlr = dlr; a.Fdiv = Fdiv;
+    a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
+    a.norm_partials = norm_partials;
+    dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
+    if (VEC == 4) {
+        hipLaunchKernelGGL(chunk_reduce_kernel<4>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL(segment_finalize_kernel<4>, grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(chunk_reduce_kernel<1>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL(segment_finalize_kernel<1>, grid, block, 0, stream, a);
+    }
+    RS_CHECK_LAUNCH("rs_sparse_bwd_reduce");
+    return RS_OK;
+}
+
+static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, int* VEC) {
+    const int* p = plan;
+    p += (size_t)F * cap; p += (size_t)F * (cap + 1);
+    a.seg_row = p; p += (size_t)F * cap; p += (size_t)F * (cap + 1);
+    a.counts = p;
+    a.F = F; a.cap = cap; a.d = d;
+    return lanes_for(d, VEC, &a.C);
+}
+
+// Optimizer step on the touched rows only.  opt: 0 SGD, 1 Adam, 2 AdamW, 3 Adagrad (state in m).
+int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                     float* table, float* m, float* v, float* table1, float* m1, float* v1,
+                     const float* hyper, const float* scal, hipStream_t stream) {
+    RS_CHECK_ARG(plan && hyper, "rs_sparse_update: null argument");
+    RS_CHECK_ARG(opt >= 0 && opt <= 3, "rs_sparse_update: unknown optimizer %d", opt);
+    RS_CHECK_ARG(!table || rowgrad, "rs_sparse_update: table without rowgrad");
+    RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_update: table1 without rowgrad1");
+    if (opt == OPT_ADAM || opt == OPT_ADAMW)
+        RS_CHECK_ARG((!table || (m && v)) && (!table1 || (m1 && v1)), "rs_sparse_update: Adam needs m and v");
+    if (opt == OPT_ADAGRAD) RS_CHECK_ARG((!table || m) && (!table1 || m1), "rs_sparse_update: Adagrad needs the sum state in m");
+    UpdateArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_update: unsupported d=%d", d);
+    a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.opt = opt; a.table = table; a.m = m; a.v = v;
+    a.table1 = table1; a.m1 = m1; a.v1 = v1; a.hyper = hyper; a.scal = scal;
+    dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(sparse_update_kernel<4>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(sparse_update_kernel<1>, grid, block, 0, stream, a);
+    RS_CHECK_LAUNCH("rs_sparse_update");
+    return RS_OK;
+}
+
+// Expand row gradients into dense gradients (which the caller zeroed): grad[row, :] = rowgrad.
+int rs_sparse_scatter_dense(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,
+                            float* grad, float* grad1, hipStream_t stream) {
+    RS_CHECK_ARG(plan, "rs_sparse_scatter_dense: null plan");
+    RS_CHECK_ARG(!grad || rowgrad, "rs_sparse_scatter_dense: grad without rowgrad");
+    RS_CHECK_ARG(!grad1 || rowgrad1, "rs_sparse_scatter_dense: grad1 without rowgrad1");
+    UpdateArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_scatter_dense: unsupported d=%d", d);
+    a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.table = grad; a.table1 = grad1;
+    dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(scatter_rowgrad_kernel<4>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(scatter_rowgrad_kernel<1>, grid, block, 0, stream, a);
+    RS_CHECK_LAUNCH("rs_sparse_scatter_dense");
+    return RS_OK;
+}
+
+// Dense optimizer step over a flat parameter buffer.
+int rs_dense_update(float* w, const float* g, float* m, float* v, long long n, int opt, const float* hyper,
+                    const float* scal, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0, "rs_dense_update: negative n");
+    if (n == 0) return RS_OK;
+    RS_CHECK_ARG(w && g && hyper, "rs_dense_update: null argument");
+    RS_CHECK_ARG(opt >= 0 && opt <= 3, "rs_dense_update: unknown optimizer %d", opt);
+    if (opt == OPT_ADAM || opt == OPT_ADAMW) RS_CHECK_ARG(m && v, "rs_dense_update: Adam needs m and v");
+    if (opt == OPT_ADAGRAD) RS_CHECK_ARG(m, "rs_dense_update: Adagrad needs the sum state in m");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dense_update_kernel, dim3(blocks), dim3(256), 0, stream, w, g, m, v, n, opt, hyper, scal, 0.f);
+    RS_CHECK_LAUNCH("rs_dense_update");
+    return RS_OK;
+}
+
+// partials[0..nblocks) = per-workgroup sums of x^2 (fixed grid => reproducible).
+int rs_sumsq_partials(const float* x, long long n, float* partials, int nblocks, hipStream_t stream) {
+    RS_CHECK_ARG(partials && nblocks > 0 && n >= 0, "rs_sumsq_partials: bad arguments");
+    RS_CHECK_ARG(x || n == 0, "rs_sumsq_partials: null input");
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(nblocks), dim3(256), 0, stream, x, n, partials);
+    RS_CHECK_LAUNCH("rs_sumsq_partials");
+    return RS_OK;
+}
+
+// scal[0] = sqrt(sum partials), scal[1] = min(1, max_norm / (scal[0] + 1e-6))
+// (nn.utils.clip_grad_norm_ as called at model/utils/BaseModel.py:148); max_norm <= 0 disables.
+int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, hipStream_t stream) {
+    RS_CHECK_ARG(partials && scal && n >= 0, "rs_clip_coef: bad arguments");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partials, n, max_norm, scal);
+    RS_CHECK_LAUNCH("rs_clip_coef");
+    return RS_OK;
+}
+
+// *step += 1 and refresh the Adam bias-correction scalars in hyper[5], hyper[6].
+int rs_opt_prepare(long long* step, float* hyper, hipStream_t stream) {
+    RS_CHECK_ARG(step && hyper, "rs_opt_prepare: null argument");
+    hipLaunchKernelGGL(opt_prepare_kernel, dim3(1), dim3(64), 0, stream, step, hyper);
+    RS_CHECK_LAUNCH("rs_opt_prepare");
+    return RS_OK;
+}
+
+}  // extern "C"

@@ -94,3 +94,237 @@ def gather_lr_fm_fwd(idx: torch.Tensor, layout: FieldLayout, table: Optional[tor
          ptr(bias), ptr(out.get("emb")), ptr(out.get("sum")), ptr(out.get("bi")), ptr(out.get("lr")),
          ptr(out.get("fm")), B, Fn, d, ptr(layout.err_flag), stream())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# workspaces: named, cached device buffers (no allocation on the steady-state path)
+# ---------------------------------------------------------------------------------------------
+class Workspace:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._bufs = {}
+
+    def get(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.dtype != dtype:
+            b = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._bufs[name] = b
+        return b
+
+
+_default_ws = {}
+
+
+def default_workspace(device) -> Workspace:
+    device = torch.device(device)
+    key = (device.type, device.index)
+    if key not in _default_ws:
+        _default_ws[key] = Workspace(device)
+    return _default_ws[key]
+
+
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "tanh": 2, "leakyrelu": 3, "prelu": 4}
+OPT_CODES = {"SGD": 0, "Adam": 1, "AdamW": 2, "Adagrad": 3}
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
+         mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None) -> torch.Tensor:
+    """C = epi(op(A) op(B)) in fp32 on the matrix cores.
+
+    a_mc=False: a is [M, K];  a_mc=True: a is [K, M] (used as its transpose).
+    b_nc=False: b is [N, K] (nn.Linear weight);  b_nc=True: b is [K, N].
+    """
+    _chk(a, torch.float32, "a")
+    _chk(b, torch.float32, "b")
+    if a.dim() != 2 or b.dim() != 2:
+        raise RSError("gemm: operands must be 2-D")
+    M, K = (a.shape[1], a.shape[0]) if a_mc else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if b_nc else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise RSError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    _chk(bias, torch.float32, "bias", (N,))
+    _chk(mulsrc, torch.float32, "mulsrc", (M, N))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        _chk(out, torch.float32, "out", (M, N))
+    if M == 0 or N == 0:
+        return out
+    h = _lib.lib()
+    if splitk <= 0 or tile < 0:
+        import ctypes as C
+        sk = C.c_int(1)
+        t = h.rs_gemm_plan(M, N, K, 256, C.byref(sk))
+        if tile < 0:
+            tile = t
+        if splitk <= 0:
+            splitk = sk.value
+    wbuf, wbytes = None, 0
+    if splitk > 1:
+        ws = ws or default_workspace(a.device)
+        wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
+        wbuf = ws.get("gemm_splitk", wbytes // 4)
+    call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), a.shape[1], ptr(b), b.shape[1], ptr(out), N,
+         ptr(bias), int(act), ptr(mulsrc), N, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, stream())
+    return out
+
+
+def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    M, N = x.shape
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    ws = ws or default_workspace(x.device)
+    wbytes = _lib.lib().rs_colsum_workspace_bytes(M, N)
+    wbuf = ws.get("colsum", max(wbytes // 4, 1))
+    call("rs_colsum_f32", ptr(x), M, N, N, ptr(out), ptr(wbuf), wbytes, stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# loss head
+# ---------------------------------------------------------------------------------------------
+def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, want_dz=True, grad_scale=1.0):
+    """loss = BCE(sigmoid(sum(parts)), labels) (mean); returns dict(loss, dz, logit, prob)."""
+    parts = [p.reshape(-1) for p in parts if p is not None]
+    B = parts[0].numel()
+    for p in parts:
+        _chk(p, torch.float32, "logit part", (B,))
+    if len(parts) > 3:
+        raise RSError("bce_head: at most three logit parts")
+    parts = parts + [None] * (3 - len(parts))
+    dev = parts[0].device
+    lf = li = None
+    if labels.dtype == torch.float32:
+        lf = labels
+    elif labels.dtype == torch.int64:
+        li = labels
+    else:
+        raise RSError(f"bce_head: labels must be float32 or int64, got {labels.dtype}")
+    _chk(labels, labels.dtype, "labels", (B,))
+    out = {"loss": torch.empty(1, dtype=torch.float32, device=dev)}
+    if want_logit:
+        out["logit"] = torch.empty(B, dtype=torch.float32, device=dev)
+    if want_prob:
+        out["prob"] = torch.empty(B, dtype=torch.float32, device=dev)
+    if want_dz:
+        out["dz"] = torch.empty(B, dtype=torch.float32, device=dev)
+    call("rs_bce_head", ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), ptr(lf), ptr(li), B, ptr(out.get("logit")),
+         ptr(out.get("prob")), ptr(out["loss"]), ptr(out.get("dz")), float(grad_scale), stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse backward
+# ---------------------------------------------------------------------------------------------
+class SparsePlan:
+    """Device scratch of one sparse backward: sort/segment plan + reduction buffers.
+
+    cap = max entries per field.  Buffers are allocated once and reused every step.
+    """
+
+    CHUNK = 32          # L: max sorted entries summed sequentially by one lane group
+
+    def __init__(self, layout: FieldLayout, cap: int, d: int, with_lr: bool, device=None):
+        h = _lib.lib()
+        self.layout = layout
+        self.F = layout.num_fields
+        self.cap = int(cap)
+        self.d = int(d)
+        dev = device or layout.device
+        if cap > h.rs_sort_max_entries():
+            raise RSError(f"sparse backward: {cap} entries per field exceed the in-LDS sort limit "
+                          f"{h.rs_sort_max_entries()}")
+        self.plan = torch.zeros(h.rs_sort_plan_ints(self.F, self.cap), dtype=torch.int32, device=dev)
+        self.chunk_sum = torch.empty((self.F, self.cap, self.d), dtype=torch.float32, device=dev)
+        self.rowgrad = torch.empty((self.F, self.cap, self.d), dtype=torch.float32, device=dev)
+        self.chunk_sum1 = torch.empty((self.F, self.cap), dtype=torch.float32, device=dev) if with_lr else None
+        self.rowgrad1 = torch.empty((self.F, self.cap), dtype=torch.float32, device=dev) if with_lr else None
+        self.n_partials = h.rs_sparse_bwd_num_partials(self.F, self.cap, self.d)
+        if self.n_partials < 0:
+            raise RSError(f"sparse backward: unsupported embedding_dim {d}")
+        self._columnar = {}
+
+    # views into the plan (for tests / inspection)
+    def counts(self):
+        off = self.F * (4 * self.cap + 2)
+        return self.plan[off:off + 4 * self.F].view(self.F, 4)
+
+    def seg_rows(self):
+        off = self.F * self.cap + self.F * (self.cap + 1)
+        return self.plan[off:off + self.F * self.cap].view(self.F, self.cap)
+
+    def columnar_lists(self, B: int):
+        """Sub-list descriptors for a columnar [F, B] batch: one list per field."""
+        if B not in self._columnar:
+            dev = self.plan.device
+            f = torch.arange(self.F, dtype=torch.int32, device=dev)
+            self._columnar[B] = (f * B, torch.full((self.F,), B, dtype=torch.int32, device=dev), f.clone())
+        return self._columnar[B]
+
+    def sort_columnar(self, idx: torch.Tensor):
+        """idx [F, B] int64 -> plan.  The gradient-row index of entry (f, b) is b*F + f."""
+        Fn, B = idx.shape
+        _chk(idx, torch.int64, "idx", (self.F, B))
+        if B > self.cap:
+            raise RSError(f"sparse backward: batch {B} exceeds plan capacity {self.cap}")
+        off, cnt, base = self.columnar_lists(B)
+        call("rs_sparse_bwd_sort", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.F, 1, self.F, self.cap, B,
+             self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan), stream())
+
+    def sort_lists(self, keys, sub_off, sub_cnt, pay_base, nsrc: int, max_entries: int):
+        """General form: per field, `nsrc` packed sub-lists of keys; gradient rows are packed likewise."""
+        _chk(keys, torch.int64, "keys")
+        for t, n in ((sub_off, "sub_off"), (sub_cnt, "sub_cnt"), (pay_base, "pay_base")):
+            _chk(t, torch.int32, n, (nsrc * self.F,))
+        call("rs_sparse_bwd_sort", ptr(keys), ptr(sub_off), ptr(sub_cnt), ptr(pay_base), 1, nsrc, self.F, self.cap,
+             int(max_entries), self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan),
+             stream())
+
+    def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
+               Fdiv=None):
+        """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats)."""
+        if norm_partials.numel() < self.n_partials:
+            raise RSError("sparse backward: norm_partials too small")
+        for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
+            _chk(t, torch.float32, n)
+        call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
+             ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
+             ptr(self.rowgrad1), ptr(norm_partials), stream())
+
+    def update(self, opt: str, hyper, scal, table=None, m=None, v=None, table1=None, m1=None, v1=None):
+        call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
+             ptr(self.rowgrad1), ptr(table), ptr(m), ptr(v), ptr(table1), ptr(m1), ptr(v1), ptr(hyper), ptr(scal),
+             stream())
+
+    def scatter_dense(self, grad=None, grad1=None):
+        call("rs_sparse_scatter_dense", ptr(self.plan), self.F, self.cap, self.d, ptr(self.rowgrad),
+             ptr(self.rowgrad1), ptr(grad), ptr(grad1), stream())
+
+
+def sumsq_partials(x: torch.Tensor, partials: torch.Tensor):
+    _chk(x, torch.float32, "x")
+    call("rs_sumsq_partials", ptr(x), x.numel(), ptr(partials), partials.numel(), stream())
+
+
+def clip_coef(partials: torch.Tensor, max_norm: float, scal: torch.Tensor):
+    call("rs_clip_coef", ptr(partials), partials.numel(), float(max_norm), ptr(scal), stream())
+
+
+def dense_update(w, g, m, v, opt: str, hyper, scal):
+    _chk(w, torch.float32, "w")
+    _chk(g, torch.float32, "g", w.shape)
+    call("rs_dense_update", ptr(w), ptr(g), ptr(m), ptr(v), w.numel(), OPT_CODES[opt], ptr(hyper), ptr(scal), stream())
+
+
+def opt_prepare(step: torch.Tensor, hyper: torch.Tensor):
+    _chk(step, torch.int64, "step", (1,))
+    _chk(hyper, torch.float32, "hyper", (8,))
+    call("rs_opt_prepare", ptr(step), ptr(hyper), stream())
+
+
+def make_hyper(device, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    return torch.tensor([lr, beta1, beta2, eps, weight_decay, lr, 1.0, 0.0], dtype=torch.float32, device=device)

@@ -1,0 +1,125 @@
+"""K2e parity: fp32 MFMA GEMM (+ fused MLP epilogues) vs a float64 CPU product."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ACT = {"none": 0, "relu": 1, "tanh": 2, "leakyrelu": 3}
+
+
+def _ref_act(code, z):
+    if code == 1:
+        return torch.relu(z)
+    if code == 2:
+        return torch.tanh(z)
+    if code == 3:
+        return torch.nn.functional.leaky_relu(z, 0.01)
+    return z
+
+
+def _check(got, want64, bound64, rel=2e-6):
+    # |err| <= rel * sum_k |a||b|  (fp32 accumulation bound), elementwise
+    err = (got.double().cpu() - want64).abs()
+    assert (err <= rel * bound64 + 1e-30).all(), float((err / (bound64 + 1e-30)).max())
+
+
+SHAPES = [(1, 1, 1), (3, 5, 7), (64, 64, 32), (65, 63, 33), (128, 128, 64), (200, 1, 256), (256, 624, 1024),
+          (4096, 1024, 624), (512, 256, 512), (130, 260, 36), (31, 520, 14)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(M, N, K, layout):
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)          # logical B(k, n)
+    want = A.double() @ Bm.double()
+    bound = A.double().abs() @ Bm.double().abs()
+    dev = "cuda:0"
+    if layout == "nt":      # forward: B stored [N, K]
+        got = ops.gemm(A.to(dev), Bm.t().contiguous().to(dev))
+    elif layout == "nn":    # dX: B stored [K, N]
+        got = ops.gemm(A.to(dev), Bm.to(dev), b_nc=True)
+    else:                   # dW: A stored [K, M], B stored [K, N]
+        got = ops.gemm(A.t().contiguous().to(dev), Bm.to(dev), a_mc=True, b_nc=True)
+    _check(got, want, bound)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("splitk", [1, 3, 8])
+def test_gemm_tiles_and_splitk(tile, splitk):
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(tile * 10 + splitk)
+    M, N, K = 300, 200, 1000
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    want = A.double() @ W.double().t()
+    bound = A.double().abs() @ W.double().abs().t()
+    got = ops.gemm(A.cuda(), W.cuda(), tile=tile, splitk=splitk)
+    _check(got, want, bound)
+    # split-K slabs are summed in a fixed order: bitwise reproducible
+    again = ops.gemm(A.cuda(), W.cuda(), tile=tile, splitk=splitk)
+    assert torch.equal(got, again)
+    AT = A.t().contiguous().cuda()
+    got = ops.gemm(AT, W.t().contiguous().cuda(), a_mc=True, b_nc=True, tile=tile, splitk=splitk)
+    _check(got, want, bound)
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "tanh", "leakyrelu"])
+def test_gemm_forward_epilogue(act):
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 257, 130, 96
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    want = _ref_act(ACT[act], X.double() @ W.double().t() + b.double())
+    got = ops.gemm(X.cuda(), W.cuda(), bias=b.cuda(), act=ACT[act])
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    got = ops.gemm(X.cuda(), W.cuda(), bias=b.cuda(), act=ACT[act], splitk=2)
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "leakyrelu"])
+def test_gemm_backward_epilogue(act):
+    """dZ_prev = (dZ W) * act'(H_prev), act' evaluated from the stored activation output."""
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 130, 72, 50          # dZ [M, N], W [N, K], H_prev [M, K]
+    dZ = torch.randn(M, N, generator=g)
+    W = torch.randn(N, K, generator=g)
+    Zp = torch.randn(M, K, generator=g)
+    Hp = _ref_act(ACT[act], Zp)
+    if act == "relu":
+        dact = (Zp > 0).double()
+    elif act == "tanh":
+        dact = 1 - torch.tanh(Zp.double()) ** 2
+    else:
+        dact = torch.where(Zp > 0, 1.0, 0.01).double()
+    want = (dZ.double() @ W.double()) * dact
+    got = ops.gemm(dZ.cuda(), W.cuda(), b_nc=True, mulsrc=Hp.cuda(), mul_act=ACT[act])
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_colsum():
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(1)
+    for M, N in [(1, 1), (7, 5), (4096, 1024), (1000, 130), (300, 1)]:
+        X = torch.randn(M, N, generator=g)
+        got = ops.colsum(X.cuda())
+        torch.testing.assert_close(got.cpu().double(), X.double().sum(0), rtol=1e-6, atol=1e-4 * (M ** 0.5) * 1e-1)
+
+
+def test_mfma_fragment_layout_with_asymmetric_data():
+    """A = I against an asymmetric B catches a transposed C write or swapped operand lanes."""
+    from recommendsystem_amd import ops
+    n = 96
+    Bm = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) + torch.arange(n).float()[:, None] * 0.5
+    I = torch.eye(n)
+    got = ops.gemm(I.cuda(), Bm.t().contiguous().cuda())
+    assert torch.equal(got.cpu(), Bm)
+    got = ops.gemm(I.cuda(), Bm.cuda(), b_nc=True)
+    assert torch.equal(got.cpu(), Bm)
+    got = ops.gemm(I.cuda(), Bm.cuda(), a_mc=True, b_nc=True)
+    assert torch.equal(got.cpu(), Bm)

@@ -1,0 +1,226 @@
+"""K3 parity: per-field radix sort + segmented reduce + touched-rows update vs torch CPU autograd."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_batch, golden_feature_map, load_golden
+from oracle import ctr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, vocabs, seed, skew=True):
+    g = torch.Generator().manual_seed(seed)
+    cols = []
+    for v in vocabs:
+        if skew:
+            u = torch.rand(B, generator=g)
+            c = ((u ** 4) * v).long().clamp(0, v - 1)     # heavy head, includes padding row 0
+        else:
+            c = torch.randint(0, v, (B,), generator=g)
+        cols.append(c)
+    return torch.stack(cols, 0), g
+
+
+def _dense_ref(idx, vocabs, gout, d):
+    """torch CPU autograd: dense per-field gradients of sum(emb * gout), padding_idx = 0."""
+    grads = []
+    for f, v in enumerate(vocabs):
+        e = torch.nn.Embedding(v, d, padding_idx=0)
+        out = e(idx[f])
+        (out * gout[:, f]).sum().backward()
+        grads.append(e.weight.grad)
+    return torch.cat(grads, 0)
+
+
+@pytest.mark.parametrize("B,vocabs,d", [
+    (1, [4], 4), (8, [11, 7, 50, 3, 200], 4), (100, [5, 1000], 16), (4096, [10, 100, 1000, 100000, 1000000], 16),
+    (333, [50] * 7, 1), (70, [9, 33], 20), (5000, [17, 70000], 8), (16384, [100, 1 << 20], 16),
+])
+def test_row_sets_and_row_grads(B, vocabs, d):
+    from recommendsystem_amd import ops
+    idx, g = _case(B, vocabs, seed=B + d)
+    F = len(vocabs)
+    gout = torch.randn(B, F, d, generator=g)
+    want = _dense_ref(idx, vocabs, gout, d)
+
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
+    plan.sort_columnar(idx.to(dev))
+    partials = torch.zeros(plan.n_partials, device=dev)
+    plan.reduce(partials, gout=gout.to(dev).view(B * F, d))
+    grad = torch.zeros(layout.total_rows, d, device=dev)
+    plan.scatter_dense(grad=grad)
+
+    counts = plan.counts().cpu()
+    seg_rows = plan.seg_rows().cpu()
+    for f, v in enumerate(vocabs):
+        uniq = torch.unique(idx[f])
+        uniq = uniq[uniq != 0] + layout.row_offsets[f]
+        n_seg = int(counts[f, 2])
+        assert int(counts[f, 0]) == B and int(counts[f, 3]) == int((idx[f] == 0).sum())
+        assert torch.equal(seg_rows[f, :n_seg].long(), uniq)          # touched-row set, bit-exact, ascending
+    got = grad.cpu()
+    mag = _dense_ref(idx, vocabs, gout.abs(), d)
+    assert ((got - want).abs() <= 1e-6 * mag + 1e-30).all()
+    # rows touched fewer than CHUNK times are summed in the same order as torch CPU: bit-exact
+    for f, v in enumerate(vocabs):
+        cnt = torch.bincount(idx[f], minlength=v)
+        small = torch.nonzero((cnt > 0) & (cnt <= 1)).flatten()
+        small = small[small != 0] + layout.row_offsets[f]
+        assert torch.equal(got[small], want[small])
+    # gradient norm from the partials
+    torch.testing.assert_close(partials.sum().cpu().double().sqrt(), want.double().norm(), rtol=1e-5, atol=1e-12)
+    # deterministic: a second run is bitwise identical
+    plan.sort_columnar(idx.to(dev))
+    plan.reduce(partials, gout=gout.to(dev).view(B * F, d))
+    grad2 = torch.zeros_like(grad)
+    plan.scatter_dense(grad=grad2)
+    assert torch.equal(grad, grad2)
+
+
+def test_golden_table_grads():
+    from recommendsystem_amd import ops
+    g = load_golden("layers.npz")
+    fm, feats = golden_feature_map(g)
+    cols = O.categorical_columns(fm, feats)
+    x = golden_batch(g, feats)
+    vocabs = [fm[c]["vocab_size"] for c in cols]
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    idx = torch.stack([x[c].long() for c in cols], 0).to(dev)
+    gout = torch.from_numpy(g["emb_grad_out"]).to(dev)
+    B, F, d = gout.shape
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
+    plan.sort_columnar(idx)
+    partials = torch.zeros(plan.n_partials, device=dev)
+    plan.reduce(partials, gout=gout.view(B * F, d))
+    grad = torch.zeros(layout.total_rows, d, device=dev)
+    plan.scatter_dense(grad=grad)
+    want = np.concatenate([g[f"table_grad.{c}"] for c in cols], 0)
+    assert np.array_equal(grad.cpu().numpy(), want)        # tiny batch: same summation order => bit-exact
+
+
+def test_fm_and_lr_terms_fused_in_reduce():
+    """g(b,f) = gout + dfm[b]*(S[b]-e[b,f]) and the 1-dim LR gradient dlr[b], vs autograd of the oracle."""
+    from recommendsystem_amd import ops
+    B, vocabs, d = 300, [6, 40, 900], 8
+    idx, g = _case(B, vocabs, seed=3)
+    F = len(vocabs)
+    cols = [f"C{i}" for i in range(F)]
+    tables = {c: O.init_table(v, d, 0.3, g).requires_grad_(True) for c, v in zip(cols, vocabs)}
+    tables1 = {c: O.init_table(v, 1, 0.3, g).requires_grad_(True) for c, v in zip(cols, vocabs)}
+    x = {c: idx[i] for i, c in enumerate(cols)}
+    emb = O.embedding_lookup(tables, cols, x)
+    emb_pad = emb      # padding rows are zero vectors; autograd through indexing gives them grad, masked below
+    gout = torch.randn(B, F, d, generator=g)
+    dlog = torch.randn(B, generator=g)
+    loss = (emb * gout).sum() + (O.fm_second_order(emb).squeeze(1) * dlog).sum() \
+        + (O.lr_forward(tables1, torch.zeros(1), cols, x).squeeze(1) * dlog).sum()
+    loss.backward()
+    want = torch.cat([tables[c].grad for c in cols], 0)
+    want1 = torch.cat([tables1[c].grad for c in cols], 0).squeeze(1)
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    for off in layout.row_offsets:          # padding_idx rows never receive gradient in the reference
+        want[off] = 0
+        want1[off] = 0
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=True)
+    plan.sort_columnar(idx.to(dev))
+    partials = torch.zeros(plan.n_partials, device=dev)
+    embd = emb.detach().to(dev).contiguous()
+    plan.reduce(partials, gout=gout.to(dev).view(B * F, d), dfm=dlog.to(dev), S=embd.sum(1).contiguous(),
+                emb=embd.view(B * F, d), dlr=dlog.to(dev))
+    grad = torch.zeros(layout.total_rows, d, device=dev)
+    grad1 = torch.zeros(layout.total_rows, device=dev)
+    plan.scatter_dense(grad=grad, grad1=grad1)
+    torch.testing.assert_close(grad.cpu(), want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(grad1.cpu(), want1, rtol=1e-4, atol=1e-5)
+    nrm = (want.double().pow(2).sum() + want1.double().pow(2).sum()).sqrt()
+    torch.testing.assert_close(partials.sum().cpu().double().sqrt(), nrm, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "AdamW", "Adagrad"])
+def test_sparse_update_matches_torch_on_touched_rows(opt):
+    """Three steps; rows touched in every step must match the dense torch optimizer; rows never touched
+    must not move (torch moves them too only through Adam momentum, which they do not have)."""
+    from recommendsystem_amd import ops
+    B, vocabs, d = 64, [5, 30], 4
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    g = torch.Generator().manual_seed(11)
+    W0 = torch.randn(layout.total_rows, d, generator=g)
+    W = W0.clone().to(dev)
+    m = torch.zeros_like(W)
+    v = torch.zeros_like(W)
+    ref = W0.clone().requires_grad_(True)
+    topt = O.make_optimizer(opt, [ref], 0.05)
+    hyper = ops.make_hyper(dev, 0.05, weight_decay=0.01 if opt == "AdamW" else 0.0,
+                           eps=1e-10 if opt == "Adagrad" else 1e-8)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    scal = torch.tensor([0.0, 1.0], device=dev)
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
+    # the same batch every step so that every touched row is touched in every step (dense == lazy there)
+    idx = torch.stack([torch.randint(1, vv, (B,), generator=g) for vv in vocabs], 0)
+    for s in range(3):
+        gout = torch.randn(B, 2, d, generator=g)
+        topt.zero_grad()
+        rows = idx + torch.tensor(layout.row_offsets)[:, None]
+        (ref[rows.t()] * gout).sum().backward()
+        topt.step()
+        ops.opt_prepare(step, hyper)
+        plan.sort_columnar(idx.to(dev))
+        partials = torch.zeros(plan.n_partials, device=dev)
+        plan.reduce(partials, gout=gout.to(dev).view(B * 2, d))
+        plan.update(opt, hyper, scal, table=W, m=m, v=v)
+    touched = torch.unique(rows)
+    torch.testing.assert_close(W.cpu()[touched], ref.detach()[touched], rtol=2e-5, atol=1e-6)
+    untouched = torch.tensor([r for r in range(layout.total_rows) if r not in set(touched.tolist())])
+    assert torch.equal(W.cpu()[untouched], W0[untouched])
+    assert int(step.item()) == 3
+
+
+def test_clip_coef_and_dense_update():
+    from recommendsystem_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(2)
+    w0 = torch.randn(10000, generator=g)
+    grad = torch.randn(10000, generator=g) * 3
+    ref = w0.clone().requires_grad_(True)
+    topt = torch.optim.Adam([ref], lr=1e-2)
+    w = w0.clone().to(dev); m = torch.zeros_like(w); v = torch.zeros_like(w)
+    hyper = ops.make_hyper(dev, 1e-2)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    scal = torch.zeros(2, device=dev)
+    partials = torch.zeros(64, device=dev)
+    for s in range(4):
+        ref.grad = grad.clone() * (s + 1)
+        tn = torch.nn.utils.clip_grad_norm_([ref], 10.0)
+        topt.step()
+        gd = (grad * (s + 1)).to(dev)
+        ops.opt_prepare(step, hyper)
+        ops.sumsq_partials(gd, partials)
+        ops.clip_coef(partials, 10.0, scal)
+        torch.testing.assert_close(scal[0].cpu(), tn, rtol=1e-5, atol=0)
+        ops.dense_update(w, gd, m, v, "Adam", hyper, scal)
+    torch.testing.assert_close(w.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_bce_head_matches_torch():
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B = 4096
+    z0 = (torch.randn(B, generator=g) * 3).requires_grad_(True)
+    z1 = torch.randn(B, generator=g)
+    z1[:4] = torch.tensor([60.0, -60.0, 120.0, -120.0])     # saturation: log clamp at -100 and grad floor 1e-12
+    y = (torch.rand(B, generator=g) < 0.3).long()
+    p = torch.sigmoid(z0 + z1)
+    loss = torch.nn.functional.binary_cross_entropy(p, y.float())
+    loss.backward()
+    out = ops.bce_head([z0.detach().cuda(), z1.cuda()], y.cuda(), want_logit=True, want_prob=True)
+    torch.testing.assert_close(out["loss"].cpu()[0], loss.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["prob"].cpu(), p.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(out["dz"].cpu(), z0.grad, rtol=1e-4, atol=1e-9)
+    out2 = ops.bce_head([z0.detach().cuda(), z1.cuda()], y.float().cuda())
+    assert torch.equal(out2["dz"], out["dz"])
