@@ -52,6 +52,11 @@ _SIGS = {
     "rs_ln_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_ln_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_add_f32": [c_f32p, c_f32p, c_f32p, L, c_stream],
+    "rs_axpy_f32": [F, c_f32p, c_f32p, L, c_stream],
+    "rs_loss_add_reg": [c_f32p, c_f32p, c_i32p, c_f32p, I, c_stream],
+    # interact.hip
+    "rs_fm_fwd": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_fm_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
 }
 # entry points that do not follow the "returns int status" convention: name -> (restype, argtypes)
 _PLAIN = {

@@ -221,6 +221,28 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + b[i];
 }
 
+// y += a * x, flat
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* __restrict__ x, float* __restrict__ y,
+                                                   long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+
+// out[0] = base[0] + sum_i coef[i] * partial_sums_i  (adds the L2 penalty terms to the loss)
+__global__ void loss_add_reg_kernel(float* loss, const float* __restrict__ partials, const int* __restrict__ seg_end,
+                                    const float* __restrict__ coef, int nseg) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float l = loss[0];
+    int beg = 0;
+    for (int s = 0; s < nseg; ++s) {
+        float t = 0.f;
+        for (int i = beg; i < seg_end[s]; ++i) t += partials[i];
+        l += coef[s] * t;
+        beg = seg_end[s];
+    }
+    loss[0] = l;
+}
+
 int flat_blocks(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -315,6 +337,24 @@ int rs_ln_bwd(const float* dh, const float* h, const float* xhat, const float* r
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(rs_cdiv(M, 4)), dim3(256), 0, stream, dh, h, xhat, rstd, gamma, M, N, act, dz,
                        dy, dyxhat);
     RS_CHECK_LAUNCH("rs_ln_bwd");
+    return RS_OK;
+}
+
+// y += a * x  (L2 regularisation gradient lambda * w, model/utils/BaseModel.py:214-231)
+int rs_axpy_f32(float a, const float* x, float* y, long long n, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "rs_axpy_f32: bad arguments");
+    if (n == 0) return RS_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(flat_blocks(n)), dim3(256), 0, stream, a, x, y, n);
+    RS_CHECK_LAUNCH("rs_axpy_f32");
+    return RS_OK;
+}
+
+// loss[0] += sum_s coef[s] * sum(partials[seg_end[s-1] : seg_end[s]])   (single thread, fixed order)
+int rs_loss_add_reg(float* loss, const float* partials, const int* seg_end, const float* coef, int nseg,
+                    hipStream_t stream) {
+    RS_CHECK_ARG(loss && partials && seg_end && coef && nseg >= 0, "rs_loss_add_reg: bad arguments");
+    hipLaunchKernelGGL(loss_add_reg_kernel, dim3(1), dim3(64), 0, stream, loss, partials, seg_end, coef, nseg);
+    RS_CHECK_LAUNCH("rs_loss_add_reg");
     return RS_OK;
 }
 

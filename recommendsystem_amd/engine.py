@@ -1,0 +1,393 @@
+"""Fused training step: the whole of BaseModel.train_step (model/utils/BaseModel.py:141-150) as one
+sequence of HIP kernels with no host synchronisation, optionally replayed from a HIP graph.
+
+    K1  fused gather (+ LR sum, + FM sum-square)         rs_gather_lr_fm_fwd
+    MLP forward GEMMs with bias+activation epilogues     rs_gemm_f32 (...)
+    loss head: sigmoid + BCE + dL/dlogit                 rs_bce_head
+    MLP backward GEMMs (dW split over the batch)         rs_gemm_f32, rs_colsum_f32
+    K3  sort / segment / reduce of embedding gradients   rs_sparse_bwd_sort, rs_sparse_bwd_reduce
+    global-norm clip coefficient (device scalar)         rs_sumsq_partials, rs_clip_coef
+    optimizer: dense towers + touched embedding rows     rs_opt_prepare, rs_dense_update, rs_sparse_update
+
+Two embedding-update modes:
+
+* ``mode="sparse"`` (default, the fast path): optimizer state and weights of touched rows only.
+  Identical to the reference's dense optimizers for SGD and Adagrad; for Adam/AdamW it is the
+  "lazy" variant (rows absent from a batch keep their weights and moments), which differs from
+  dense Adam on rows with non-zero momentum that the batch does not touch.  Needs
+  ``emb_regular`` to be off (an L2 term on the tables gives every row a gradient).
+* ``mode="dense"``: the reference's exact semantics -- row gradients are expanded into full-table
+  gradients, L2 terms are added, and dense optimizer kernels sweep every table.  Used for
+  bit-for-semantics parity tests and as the AUC reference for the sparse mode.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import functional as Fn
+from . import ops
+from ._lib import RSError
+from .layers import MLPBlock
+from .ops import ACT_CODES
+
+_FUSABLE = (0, 1, 2, 3)
+N_DENSE_PARTIALS = 256
+
+
+class FusedTrainer:
+    def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
+                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None):
+        kind = getattr(model, "KIND", None)
+        if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
+            raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
+        if mode not in ("sparse", "dense"):
+            raise ValueError("mode must be 'sparse' or 'dense'")
+        self.model = model
+        self.kind = kind
+        self.mode = mode
+        self.max_norm = float(max_norm)
+        self.opt = optimizer_type or model.optimizer_type
+        if self.opt not in ops.OPT_CODES:
+            raise ValueError("Invalid value for optimizer")
+        self.lr = float(lr if lr is not None else model.learning_rate)
+        self.emb_reg = model.emb_regular or 0.0
+        self.net_reg = model.net_regular or 0.0
+        if mode == "sparse" and self.emb_reg:
+            raise RSError("FusedTrainer(mode='sparse'): emb_regular puts a gradient on every table row; "
+                          "use mode='dense' or turn emb_regular off")
+        self.dist = dist
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RSError("FusedTrainer: the model must live on the MI355X (there is no CPU path)")
+        self.device = dev
+        self.ws = ops.Workspace(dev)
+
+        self.has_lr = kind in ("lr", "fm", "deepfm", "widedeep")
+        self.has_emb = kind != "lr"
+        self.has_fm = kind in ("fm", "deepfm")
+        self.lrm = getattr(model, "lr_layer", None) or getattr(model, "wide", None) if self.has_lr else None
+        stack = getattr(model, "deep", None) or getattr(model, "mlp", None)
+        self.blocks: List[MLPBlock] = list(stack) if (stack is not None and kind in ("deepfm", "dnn", "widedeep")) else []
+        for b in self.blocks:
+            if not isinstance(b, MLPBlock):
+                raise RSError("FusedTrainer: the deep tower must be a stack of MLPBlock")
+            if b.dropout.p:
+                raise RSError("FusedTrainer: dropout > 0 is not part of the fused step")
+
+        emb = model.embedding_layer
+        self.cols = emb.lookup_columns
+        self.F = len(self.cols)
+        self.d = emb.embedding_dim if self.has_emb else 1
+        self.tab = emb._tab if self.has_emb else None
+        self.tab1 = self.lrm.scalar._tab1 if self.has_lr else None
+        self.layout = (self.tab or self.tab1).layout
+        if self.layout is None:
+            raise RSError("FusedTrainer: embedding tables are not on the device")
+        # tables the reference owns but never looks up (they matter only under L2 regularisation)
+        self.unused = []
+        if mode == "dense" and self.emb_reg:
+            if self.has_emb:
+                self.unused.append(emb._tab1)
+            else:
+                self.unused += [emb._tab, emb._tab1]
+            if self.has_lr:
+                self.unused.append(self.lrm.scalar._tab)
+
+        self._flatten_dense()
+        self._alloc_state()
+        self._plans: Dict[int, ops.SparsePlan] = {}
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_B = None
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _dense_params(self):
+        ps = []
+        if self.has_lr:
+            ps.append(self.lrm.bias)
+        for b in self.blocks:
+            ps += [b.fc.weight, b.fc.bias]
+            if b.normalization:
+                ps += [b.norm_layer.weight, b.norm_layer.bias]
+            if b._act == ACT_CODES["prelu"]:
+                ps.append(b.activation_func.weight)
+        return ps
+
+    def _flatten_dense(self):
+        """All dense parameters in one flat fp32 buffer (one optimizer launch, one all-reduce);
+        the nn.Parameters become views into it."""
+        ps = self._dense_params()
+        n = sum(p.numel() for p in ps)
+        # keep every view 16-byte aligned so the GEMM loaders can use 16-byte loads
+        offs, o = [], 0
+        for p in ps:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        self.flat_w = torch.zeros(max(o, 4), dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros_like(self.flat_w)
+        self.gviews = {}
+        with torch.no_grad():
+            for p, off in zip(ps, offs):
+                v = self.flat_w[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                self.gviews[id(p)] = self.flat_g[off:off + p.numel()].view_as(p)
+        self.n_dense = o
+
+    def _alloc_state(self):
+        dev = self.device
+        adam = self.opt in ("Adam", "AdamW")
+        need_m = adam or self.opt == "Adagrad"
+        z = lambda t: torch.zeros_like(t)
+        self.flat_m = z(self.flat_w) if need_m else None
+        self.flat_v = z(self.flat_w) if adam else None
+        self.tables = []           # (stacked weight, m, v, dense grad or None, used?)
+        for tab, used in ([(self.tab, True)] if self.tab else []) + ([(self.tab1, True)] if self.tab1 else []) + \
+                [(t, False) for t in self.unused]:
+            w = tab.stacked
+            g = z(w) if self.mode == "dense" else None
+            self.tables.append({"tab": tab, "w": w, "m": z(w) if need_m else None, "v": z(w) if adam else None,
+                                "g": g, "used": used})
+        wd = 0.01 if self.opt == "AdamW" else 0.0
+        eps = 1e-10 if self.opt == "Adagrad" else 1e-8
+        self.hyper = ops.make_hyper(dev, self.lr, eps=eps, weight_decay=wd)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.scal = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
+
+    def _table_entry(self, tab):
+        for t in self.tables:
+            if t["tab"] is tab:
+                return t
+        return None
+
+    def decay_lr(self, factor=0.1, min_lr=1e-6):
+        self.lr = max(self.lr * factor, min_lr)
+        self.hyper[0:1].fill_(self.lr)
+        return self.lr
+
+    def plan(self, B: int) -> ops.SparsePlan:
+        if B not in self._plans:
+            p = ops.SparsePlan(self.layout, cap=B, d=self.d, with_lr=self.has_lr)
+            n_extra = N_DENSE_PARTIALS * (1 + len(self.tables))
+            p.partials = torch.zeros(p.n_partials + n_extra, dtype=torch.float32, device=self.device)
+            self._plans[B] = p
+        return self._plans[B]
+
+    # ------------------------------------------------------------------------------------------
+    def forward_parts(self, idx: torch.Tensor):
+        """Forward pass; returns (logit parts, saved context)."""
+        B = idx.shape[1]
+        ctx = {"idx": idx, "B": B}
+        parts = []
+        table = self.tab.stacked if self.has_emb else None
+        table1 = self.tab1.stacked if self.has_lr else None
+        bias = self.lrm.bias.data if self.has_lr else None
+        r = ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
+                                 want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
+        ctx["emb"] = r.get("emb")
+        ctx["S"] = r.get("sum")
+        if self.has_lr:
+            parts.append(r["lr"])
+        if self.has_fm:
+            parts.append(r["fm"])
+        if self.blocks:
+            h = r["emb"].view(B, self.F * self.d)
+            cs = []
+            for b in self.blocks:
+                gamma = beta = rm = rv = slope = None
+                eps = 1e-5
+                if b.normalization:
+                    gamma, beta, eps = b.norm_layer.weight.data, b.norm_layer.bias.data, b.norm_layer.eps
+                    if b.normalization == "bn":
+                        rm, rv = b.norm_layer.running_mean, b.norm_layer.running_var
+                if b._act == ACT_CODES["prelu"]:
+                    slope = b.activation_func.weight.data
+                h, c = Fn.mlp_block_fwd(h, b.fc.weight.data, b.fc.bias.data, b._act, b.normalization or None, gamma,
+                                        beta, slope, self.model.training, rm, rv, eps)
+                cs.append(c)
+            ctx["mlp"] = cs
+            parts.append(h.view(B))
+        return parts, ctx
+
+    def _bump_bn_counters(self):
+        for b in self.blocks:
+            if b.normalization == "bn" and self.model.training:
+                b.norm_layer.num_batches_tracked.add_(1)
+
+    def logits(self, idx: torch.Tensor) -> torch.Tensor:
+        """Forward only.  In training mode BatchNorm running statistics move, as in a module forward."""
+        self._bump_bn_counters()
+        with ops.use_workspace(self.ws):
+            parts, _ = self.forward_parts(idx)
+            out = parts[0]
+            for p in parts[1:]:
+                out = ops.add(out, p)
+        return out.view(-1, 1)
+
+    def _step_impl(self, idx: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        B = idx.shape[1]
+        plan = self.plan(B)
+        parts, ctx = self.forward_parts(idx)
+        head = ops.bce_head(parts, labels, want_dz=True)
+        loss, dz = head["loss"], head["dz"]
+
+        # ---- dense backward ------------------------------------------------------------------
+        gout = None
+        if self.has_lr:
+            ops.colsum(dz.view(B, 1), out=self.gviews[id(self.lrm.bias)])
+        if self.blocks:
+            cs = ctx["mlp"]
+            dh = dz.view(B, 1)
+            dz_ready = False
+            for i in range(len(self.blocks) - 1, -1, -1):
+                b, c = self.blocks[i], cs[i]
+                prev = self.blocks[i - 1] if i > 0 else None
+                fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
+                r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
+                                     dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
+                                     mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0)
+                if b.normalization:
+                    self.gviews[id(b.norm_layer.weight)].copy_(r["dgamma"])
+                    self.gviews[id(b.norm_layer.bias)].copy_(r["dbeta"])
+                if r["dslope"] is not None:
+                    self.gviews[id(b.activation_func.weight)].copy_(r["dslope"])
+                dh, dz_ready = r["dx"], fuse_prev
+            gout = dh.view(B * self.F, self.d)
+
+        # ---- embedding backward: sort, segment, reduce ----------------------------------------
+        P = plan.partials
+        n_sp = plan.n_partials
+        plan.sort_columnar(idx)
+        plan.reduce(P[:n_sp], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
+                    emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
+                    dlr=dz if self.has_lr else None, Fdiv=self.F)
+
+        # ---- L2 terms, global norm, clip coefficient ------------------------------------------
+        if self.net_reg:
+            ops.axpy(self.net_reg, self.flat_w, self.flat_g)
+        if self.dist is not None:
+            self.dist.allreduce_dense(self.flat_g)
+        dense_p = P[n_sp:n_sp + N_DENSE_PARTIALS]
+        ops.sumsq_partials(self.flat_g, dense_p)
+        if self.mode == "sparse":
+            norm_in = P[:n_sp + N_DENSE_PARTIALS]
+        else:
+            off = n_sp + N_DENSE_PARTIALS
+            for t in self.tables:
+                t["g"].zero_()
+            te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+            plan.scatter_dense(grad=te["g"] if te else None, grad1=t1["g"].view(-1) if t1 else None)
+            for t in self.tables:
+                if self.emb_reg:
+                    ops.axpy(self.emb_reg, t["w"], t["g"])
+                ops.sumsq_partials(t["g"], P[off:off + N_DENSE_PARTIALS])
+                off += N_DENSE_PARTIALS
+            norm_in = P[n_sp:off]
+        ops.clip_coef(norm_in, self.max_norm, self.scal)
+        if self.net_reg or self.emb_reg:
+            loss = self._add_reg_to_loss(loss)
+
+        # ---- optimizer --------------------------------------------------------------------------
+        ops.opt_prepare(self.step_count, self.hyper)
+        ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
+        if self.mode == "sparse":
+            te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+            plan.update(self.opt, self.hyper, self.scal,
+                        table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
+                        table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
+                        v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+        else:
+            for t in self.tables:
+                ops.dense_update(t["w"].view(-1), t["g"].view(-1), t["m"].view(-1) if t["m"] is not None else None,
+                                 t["v"].view(-1) if t["v"] is not None else None, self.opt, self.hyper, self.scal)
+        self.last = {"dz": dz, "parts": parts}
+        return loss
+
+    def _add_reg_to_loss(self, loss):
+        """loss += (net/2)*||dense||^2 + (emb/2)*sum ||table||^2, evaluated on the pre-step weights."""
+        segs, coefs = [], []
+        bufs = []
+        if self.net_reg:
+            bufs.append((self.flat_w, self.net_reg / 2))
+        if self.emb_reg and self.mode == "dense":
+            for t in self.tables:
+                bufs.append((t["w"].view(-1), self.emb_reg / 2))
+        P = self.ws.get("reg_partials", N_DENSE_PARTIALS * len(bufs))
+        for i, (buf, c) in enumerate(bufs):
+            ops.sumsq_partials(buf, P[i * N_DENSE_PARTIALS:(i + 1) * N_DENSE_PARTIALS])
+            segs.append((i + 1) * N_DENSE_PARTIALS)
+            coefs.append(c)
+        key = ("reg_desc", tuple(segs), tuple(coefs))
+        if getattr(self, "_reg_key", None) != key:
+            self._reg_seg = torch.tensor(segs, dtype=torch.int32, device=self.device)
+            self._reg_coef = torch.tensor(coefs, dtype=torch.float32, device=self.device)
+            self._reg_key = key
+        ops.call("rs_loss_add_reg", ops.ptr(loss), ops.ptr(P), ops.ptr(self._reg_seg), ops.ptr(self._reg_coef),
+                 len(bufs), ops.stream())
+        return loss
+
+    # ------------------------------------------------------------------------------------------
+    def step_tensors(self, idx: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """One training step on device-resident inputs: idx [F, B] int64, labels [B] int64/float32."""
+        if not self.use_graph:
+            with ops.use_workspace(self.ws):
+                return self._step_impl(idx, labels)
+        B = idx.shape[1]
+        if self._graph is None or self._graph_B != B or self._graph_ldtype != labels.dtype:
+            self._capture(idx, labels)
+        self._idx_static.copy_(idx)
+        self._lab_static.copy_(labels)
+        self._graph.replay()
+        return self._loss_static
+
+    def _capture(self, idx, labels):
+        self._idx_static = idx.clone()
+        self._lab_static = labels.clone()
+        self._graph_B = idx.shape[1]
+        self._graph_ldtype = labels.dtype
+        # snapshot everything a step mutates, warm up (first launches set kernel attributes), restore
+        snap = [(t, t.clone()) for t in self._mutable_state()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), ops.use_workspace(self.ws):
+            for _ in range(2):
+                self._step_impl(self._idx_static, self._lab_static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in snap:
+            t.copy_(c)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph), ops.use_workspace(self.ws):
+            self._loss_static = self._step_impl(self._idx_static, self._lab_static)
+        torch.cuda.synchronize()
+        for t, c in snap:       # capture does not execute, but keep the state exactly as before
+            t.copy_(c)
+
+    def _mutable_state(self):
+        ts = [self.flat_w, self.step_count, self.hyper, self.scal]
+        for x in (self.flat_m, self.flat_v):
+            if x is not None:
+                ts.append(x)
+        for t in self.tables:
+            ts.append(t["w"])
+            for k in ("m", "v"):
+                if t[k] is not None:
+                    ts.append(t[k])
+        for b in self.blocks:
+            if b.normalization == "bn":
+                ts += [b.norm_layer.running_mean, b.norm_layer.running_var]
+        return ts
+
+    def step(self, inputs, labels) -> torch.Tensor:
+        """BaseModel.train_step signature: dict-of-columns batch and dict of label columns."""
+        m = self.model
+        x = m.features_to_divice(inputs)
+        y = m.labels_to_device(labels)
+        idx = m.embedding_layer.index_matrix(x)
+        self._bump_bn_counters()
+        if y.dtype not in (torch.int64, torch.float32):
+            y = y.float()
+        return self.step_tensors(idx, y.contiguous())

@@ -1,0 +1,256 @@
+"""Autograd bridges between the reference-shaped nn.Modules and the HIP kernels.
+
+Forward and backward of every op run in librs_hip.so; torch is used for tensor allocation,
+views and autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_CODES, FieldLayout, SparsePlan
+
+_FUSABLE = (0, 1, 2, 3)      # none / relu / tanh / leakyrelu can ride in the GEMM epilogue
+
+
+def stack_columns(x, cols) -> torch.Tensor:
+    """dict of per-column (B,) tensors -> columnar [F, B] int64 index matrix (one copy)."""
+    ts = [x[c] for c in cols]
+    if all(t.dtype == torch.int64 for t in ts):
+        return torch.stack(ts, 0)
+    return torch.stack([t.long() for t in ts], 0)      # Layers.py:147 `.long()`
+
+
+# -------------------------------------------------------------------------------------------------
+# embedding lookup (d-dim and 1-dim) with dense per-column gradients
+# -------------------------------------------------------------------------------------------------
+class _GatherFn(torch.autograd.Function):
+    """out[b, f, :] = table[row_offset[f] + idx[f, b], :] for the stacked table behind `weights`.
+
+    `weights` are the per-column nn.Embedding weights, all views into `stacked`; the backward
+    returns per-column views into ONE dense gradient buffer filled by the sort + segmented
+    reduce + scatter kernels (deterministic; padding row 0 never receives gradient).
+    """
+
+    @staticmethod
+    def forward(ctx, idx, holder, *weights):
+        stacked = holder.stacked_for(weights)
+        out = ops.gather_fwd(idx, holder.layout, stacked)
+        ctx.holder = holder
+        ctx.save_for_backward(idx)
+        ctx.d = stacked.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        holder = ctx.holder
+        layout: FieldLayout = holder.layout
+        Fn, B = idx.shape
+        d = ctx.d
+        plan = holder.plan_for(B, d)
+        plan.sort_columnar(idx)
+        partials = ops.default_workspace(idx.device).get("gather_bwd_partials", plan.n_partials)
+        plan.reduce(partials, gout=gout.contiguous().view(B * Fn, d))
+        grad = torch.zeros((layout.total_rows, d), dtype=torch.float32, device=idx.device)
+        plan.scatter_dense(grad=grad)
+        grads = [grad[o:o + v] for o, v in zip(layout.row_offsets, layout.vocab_sizes)]
+        return (None, None, *grads)
+
+
+def embedding_lookup(idx, holder, weights) -> torch.Tensor:
+    return _GatherFn.apply(idx, holder, *weights)
+
+
+class _LRFn(torch.autograd.Function):
+    """(B, 1) = sum_f w_f[idx[f, b]] + bias   (Layers.py:107-109)."""
+
+    @staticmethod
+    def forward(ctx, idx, holder, bias, *weights1):
+        stacked1 = holder.stacked_for(weights1)
+        out = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias, want_emb=False, want_lr=True)["lr"]
+        ctx.holder = holder
+        ctx.save_for_backward(idx)
+        return out.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        holder = ctx.holder
+        layout = holder.layout
+        Fn, B = idx.shape
+        g = gout.contiguous().view(B)
+        plan = holder.plan_for(B, 1, with_lr=True)
+        plan.sort_columnar(idx)
+        partials = ops.default_workspace(idx.device).get("gather_bwd_partials", plan.n_partials)
+        plan.reduce(partials, dlr=g)
+        grad1 = torch.zeros((layout.total_rows, 1), dtype=torch.float32, device=idx.device)
+        plan.scatter_dense(grad1=grad1)
+        grads = [grad1[o:o + v] for o, v in zip(layout.row_offsets, layout.vocab_sizes)]
+        dbias = ops.colsum(g.view(B, 1))
+        return (None, None, dbias, *grads)
+
+
+def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
+    return _LRFn.apply(idx, holder, bias, *weights1)
+
+
+# -------------------------------------------------------------------------------------------------
+# MLP blocks
+# -------------------------------------------------------------------------------------------------
+class MLPCtx:
+    __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps")
+
+
+def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=None, slope=None, training=True,
+                  running_mean=None, running_var=None, eps=1e-5):
+    """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx)."""
+    c = MLPCtx()
+    c.x, c.W, c.act, c.norm, c.gamma, c.slope, c.eps = x2d, W, act, norm, gamma, slope, eps
+    c.z = c.y = c.xhat = c.var = c.rstd = None
+    fus = act if act in _FUSABLE else 0
+    if not norm:
+        if act in _FUSABLE:
+            c.h = ops.gemm(x2d, W, bias=b, act=act)
+        else:                                   # PReLU: keep z for the slope gradient
+            c.z = ops.gemm(x2d, W, bias=b)
+            c.h = ops.act_fwd(c.z, act, slope)
+        return c.h, c
+    z = ops.gemm(x2d, W, bias=b)
+    if norm == "bn":
+        y, c.xhat, c.var = ops.bn_fwd(z, gamma, beta, fus, training, running_mean, running_var, eps)
+    elif norm == "ln":
+        y, c.xhat, c.rstd = ops.ln_fwd(z, gamma, beta, fus, eps)
+    else:
+        raise ValueError("normalization must be either 'bn' or 'ln' or None")
+    if act in _FUSABLE:
+        c.h = y
+    else:
+        c.y = y
+        c.h = ops.act_fwd(y, act, slope)
+    return c.h, c
+
+
+def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0):
+    """Backward of one block.  Returns dict(dx, dW, db, dgamma, dbeta, dslope).
+
+    dz_ready: `dh` already is dL/dz (the caller fused act' into the GEMM that produced it).
+    mulsrc/mul_act: fuse the PREVIOUS block's act' into this block's dx GEMM, so that the returned
+    dx is the previous block's dL/dz."""
+    out = {"dgamma": None, "dbeta": None, "dslope": None}
+    fus = c.act if c.act in _FUSABLE else 0
+    if not c.norm:
+        if dz_ready:
+            dz = dh
+        elif c.act in _FUSABLE:
+            dz = ops.act_bwd(dh, c.act, h=c.h)[0] if c.act != 0 else dh
+        else:
+            dz, out["dslope"] = ops.act_bwd(dh, c.act, z=c.z, slope=c.slope)
+    else:
+        if c.act not in _FUSABLE:
+            dh, out["dslope"] = ops.act_bwd(dh, c.act, z=c.y, slope=c.slope)
+            hh = c.y
+        else:
+            hh = c.h
+        if c.norm == "bn":
+            dz, out["dgamma"], out["dbeta"] = ops.bn_bwd(dh, hh, c.xhat, fus, c.gamma, c.var, c.eps)
+        else:
+            dz, out["dgamma"], out["dbeta"] = ops.ln_bwd(dh, hh, c.xhat, c.rstd, c.gamma, fus)
+    out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out)
+    out["db"] = ops.colsum(dz, out=db_out)
+    out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act) if need_dx else None
+    out["dz"] = dz
+    return out
+
+
+class _MLPBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps):
+        h, c = mlp_block_fwd(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps)
+        ctx.c = c
+        ctx.has = (gamma is not None, slope is not None)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0])
+        return (r["dx"], r["dW"], r["db"], r["dgamma"], r["dbeta"], r["dslope"], None, None, None, None, None, None)
+
+
+def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):
+    return _MLPBlockFn.apply(x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps)
+
+
+class _ResidualFn(torch.autograd.Function):
+    """identity (or downsample(x)) + act(norm(fc(x)))   (Layers.py:84-94)."""
+
+    @staticmethod
+    def forward(ctx, x2d, W, b, gamma, beta, Wd, bd, act, norm, training, running_mean, running_var, eps):
+        h, c = mlp_block_fwd(x2d, W, b, act, norm, gamma, beta, None, training, running_mean, running_var, eps)
+        ident = x2d if Wd is None else ops.gemm(x2d, Wd, bias=bd)
+        ctx.c = c
+        ctx.Wd = Wd
+        return ops.add(ident, h)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        c = ctx.c
+        r = mlp_block_bwd(dout, c, need_dx=True)
+        dWd = dbd = None
+        if ctx.Wd is None:
+            dx = ops.add(r["dx"], dout)
+        else:
+            dWd = ops.gemm(dout, c.x, a_mc=True, b_nc=True)
+            dbd = ops.colsum(dout)
+            dx = ops.add(r["dx"], ops.gemm(dout, ctx.Wd, b_nc=True))
+        return (dx, r["dW"], r["db"], r["dgamma"], r["dbeta"], dWd, dbd, None, None, None, None, None, None)
+
+
+def residual_block(x2d, W, b, gamma, beta, Wd, bd, act, norm, training, running_mean, running_var, eps=1e-5):
+    return _ResidualFn.apply(x2d, W, b, gamma, beta, Wd, bd, act, norm, training, running_mean, running_var, eps)
+
+
+# -------------------------------------------------------------------------------------------------
+# interactions
+# -------------------------------------------------------------------------------------------------
+class _FMFn(torch.autograd.Function):
+    """(B, 1) = 0.5 * sum_k((sum_f e)^2 - sum_f e^2)   (model/FM/FM.py:27-30)."""
+
+    @staticmethod
+    def forward(ctx, emb):
+        emb = emb.contiguous()
+        r = ops.fm_fwd(emb, want_sum=True, want_fm=True)
+        ctx.save_for_backward(emb, r["sum"])
+        return r["fm"].view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, S = ctx.saved_tensors
+        return ops.fm_bwd(emb, S, dfm=g.contiguous().view(-1))
+
+
+def fm_second_order(emb):
+    return _FMFn.apply(emb)
+
+
+class _BiInteractionFn(torch.autograd.Function):
+    """(B, d) = 0.5 * ((sum_f e)^2 - sum_f e^2): textbook NFM Bi-Interaction pooling."""
+
+    @staticmethod
+    def forward(ctx, emb):
+        emb = emb.contiguous()
+        r = ops.fm_fwd(emb, want_sum=True, want_bi=True, want_fm=False)
+        ctx.save_for_backward(emb, r["sum"])
+        return r["bi"]
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, S = ctx.saved_tensors
+        return ops.fm_bwd(emb, S, dbi=g.contiguous())
+
+
+def bi_interaction(emb):
+    return _BiInteractionFn.apply(emb)

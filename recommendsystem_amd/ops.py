@@ -113,9 +113,28 @@ class Workspace:
 
 
 _default_ws = {}
+_ws_override = []
+
+
+class use_workspace:
+    """Context manager: route every op's scratch requests to `ws` (the engine keeps its scratch
+    separate so that buffers captured in a HIP graph are never handed to eager callers)."""
+
+    def __init__(self, ws: Workspace):
+        self.ws = ws
+
+    def __enter__(self):
+        _ws_override.append(self.ws)
+        return self.ws
+
+    def __exit__(self, *exc):
+        _ws_override.pop()
+        return False
 
 
 def default_workspace(device) -> Workspace:
+    if _ws_override:
+        return _ws_override[-1]
     device = torch.device(device)
     key = (device.type, device.index)
     if key not in _default_ws:
@@ -328,3 +347,112 @@ def opt_prepare(step: torch.Tensor, hyper: torch.Tensor):
 
 def make_hyper(device, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     return torch.tensor([lr, beta1, beta2, eps, weight_decay, lr, 1.0, 0.0], dtype=torch.float32, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# activation / normalisation kernels
+# ---------------------------------------------------------------------------------------------
+def act_fwd(z: torch.Tensor, act: int, slope=None) -> torch.Tensor:
+    _chk(z, torch.float32, "z")
+    h = torch.empty_like(z)
+    call("rs_act_fwd", ptr(z), ptr(h), z.numel(), int(act), ptr(slope), stream())
+    return h
+
+
+def act_bwd(dh: torch.Tensor, act: int, z=None, h=None, slope=None):
+    """dz = dh * act'(.); returns (dz, dslope or None)."""
+    _chk(dh, torch.float32, "dh")
+    dz = torch.empty_like(dh)
+    n = dh.numel()
+    parts = None
+    if act == ACT_CODES["prelu"]:
+        parts = torch.empty(_lib.lib().rs_act_bwd_num_partials(n), dtype=torch.float32, device=dh.device)
+    call("rs_act_bwd", ptr(dh), ptr(z), ptr(h), ptr(dz), n, int(act), ptr(slope), ptr(parts), stream())
+    return dz, (colsum(parts.view(-1, 1)) if parts is not None else None)
+
+
+def bn_fwd(z, gamma, beta, act: int, training: bool, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """Returns (h, xhat, var_used).  In eval mode the running statistics are used."""
+    _chk(z, torch.float32, "z")
+    M, N = z.shape
+    h = torch.empty_like(z)
+    xhat = torch.empty_like(z)
+    if training:
+        mean = torch.empty(N, dtype=torch.float32, device=z.device)
+        var = torch.empty(N, dtype=torch.float32, device=z.device)
+    else:
+        mean, var = running_mean, running_var
+    call("rs_bn_fwd", ptr(z), M, N, ptr(gamma), ptr(beta), float(eps), int(act), int(training), float(momentum),
+         ptr(mean), ptr(var), ptr(running_mean) if training else None, ptr(running_var) if training else None,
+         ptr(xhat), ptr(h), stream())
+    return h, xhat, var
+
+
+def bn_bwd(dh, h, xhat, act: int, gamma, var, eps=1e-5):
+    M, N = dh.shape
+    dz = torch.empty_like(dh)
+    dgamma = torch.empty(N, dtype=torch.float32, device=dh.device)
+    dbeta = torch.empty(N, dtype=torch.float32, device=dh.device)
+    call("rs_bn_bwd", ptr(dh), ptr(h), ptr(xhat), M, N, int(act), ptr(gamma), ptr(var), float(eps), ptr(dgamma),
+         ptr(dbeta), ptr(dz), stream())
+    return dz, dgamma, dbeta
+
+
+def ln_fwd(z, gamma, beta, act: int, eps=1e-5):
+    M, N = z.shape
+    h = torch.empty_like(z)
+    xhat = torch.empty_like(z)
+    rstd = torch.empty(M, dtype=torch.float32, device=z.device)
+    call("rs_ln_fwd", ptr(z), M, N, ptr(gamma), ptr(beta), float(eps), int(act), ptr(xhat), ptr(rstd), ptr(h), stream())
+    return h, xhat, rstd
+
+
+def ln_bwd(dh, h, xhat, rstd, gamma, act: int):
+    M, N = dh.shape
+    dz = torch.empty_like(dh)
+    dy = torch.empty_like(dh)
+    dyx = torch.empty_like(dh)
+    call("rs_ln_bwd", ptr(dh), ptr(h), ptr(xhat), ptr(rstd), ptr(gamma), M, N, int(act), ptr(dz), ptr(dy), ptr(dyx),
+         stream())
+    return dz, colsum(dyx), colsum(dy)
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    call("rs_add_f32", ptr(a), ptr(b), ptr(y), a.numel(), stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# interactions on gathered embeddings
+# ---------------------------------------------------------------------------------------------
+def fm_fwd(emb: torch.Tensor, want_sum=True, want_bi=False, want_fm=True):
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    dev = emb.device
+    out = {}
+    if want_sum:
+        out["sum"] = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if want_bi:
+        out["bi"] = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if want_fm:
+        out["fm"] = torch.empty((B,), dtype=torch.float32, device=dev)
+    call("rs_fm_fwd", ptr(emb), B, Fn, d, ptr(out.get("sum")), ptr(out.get("bi")), ptr(out.get("fm")), stream())
+    return out
+
+
+def fm_bwd(emb, S, dfm=None, dbi=None):
+    B, Fn, d = emb.shape
+    _chk(S, torch.float32, "S", (B, d))
+    _chk(dfm, torch.float32, "dfm", (B,))
+    _chk(dbi, torch.float32, "dbi", (B, d))
+    demb = torch.empty_like(emb)
+    call("rs_fm_bwd", ptr(emb), ptr(S), ptr(dfm), ptr(dbi), B, Fn, d, ptr(demb), stream())
+    return demb
+
+
+def axpy(a: float, x: torch.Tensor, y: torch.Tensor):
+    """y += a * x (flat)."""
+    _chk(x, torch.float32, "x")
+    _chk(y, torch.float32, "y", x.shape)
+    call("rs_axpy_f32", float(a), ptr(x), ptr(y), x.numel(), stream())
