@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeepFM training step on synthetic Criteo_x1-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the environment when N > 1).  A "step" is one
+pass of the whole hot path over one batch of B samples per GPU: fused gather + LR + FM, the MLP
+GEMMs forward and backward, the loss head, the sparse embedding backward, global-norm clipping and
+the optimizer update.  Inputs are resident in HBM before the timed region starts.  Rank 0 prints
+ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch", type=int, default=4096, help="samples per GPU per step")
+    p.add_argument("--dim", type=int, default=16)
+    p.add_argument("--hidden", type=str, default="1024,512,256")
+    p.add_argument("--model", type=str, default="deepfm", choices=["deepfm", "fm", "lr", "dnn", "widedeep"])
+    p.add_argument("--optimizer", type=str, default="Adam")
+    p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
+    p.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
+    p.add_argument("--uniform", type=int, default=0, help="uniform instead of Zipf(1.1) indices")
+    p.add_argument("--cpu-baseline", type=int, default=1)
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--distinct-batches", type=int, default=8)
+    return p.parse_args()
+
+
+def build(args, device):
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd.base_model import random_all
+    random_all(2021)
+    rec = data.criteo_x1_recorder(embedding_dim=args.dim, batch_size=args.batch)
+    hidden = [int(h) for h in args.hidden.split(",") if h]
+    gpu = device.index
+    kw = dict(optimizer_type=args.optimizer)
+    if args.model == "deepfm":
+        m = models.DeepFM(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    elif args.model == "fm":
+        m = models.FM(rec, 1e-3, gpu, **kw)
+    elif args.model == "lr":
+        m = models.LR(rec, 1e-3, gpu, **kw)
+    elif args.model == "dnn":
+        m = models.DNN(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    else:
+        m = models.WideDeep(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    m.train()
+    return m, rec, hidden
+
+
+def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
+    """The CPU oracle's training step (oracle/ctr_oracle.py: per-field nn.Embedding, torch.stack,
+    sum-square, nn.Linear stack, BCE, clip_grad_norm_, dense torch optimizer) on the same batches."""
+    from oracle import ctr_oracle as O
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    torch.manual_seed(2021)
+    m = O.OracleCTRModel(args.model, rec.feature_map, rec.features, args.dim, hidden=hidden, normalization=None)
+    m.train()
+    opt = O.make_optimizer(args.optimizer, m.parameters(), 1e-3)
+    cols = rec.features
+
+    def one(i):
+        idx = idx_cpu[i % len(idx_cpu)]
+        x = {c: idx[j] for j, c in enumerate(cols)}
+        O.train_step(m, opt, x, lab_cpu[i % len(lab_cpu)])
+
+    one(0)
+    one(1)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n >= 50:
+            break
+    return {"value": n * args.batch / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {args.batch} after 2 warm-up steps, same synthetic batches, "
+                      f"torch CPU ops with {cores} threads ({el:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
+    rank = int(os.environ.get("RANK", "0")) if args.gpus > 1 else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.gpus > 1 else 0
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist_ctx = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from recommendsystem_amd.dist import ShardedTables
+        dist_ctx = ShardedTables  # constructed by the engine below
+
+    from recommendsystem_amd import data, ops
+    from recommendsystem_amd.prof import KernelTimer
+
+    model, rec, hidden = build(args, device)
+    vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
+    if world > 1:
+        from recommendsystem_amd.dist import DistributedTrainer
+        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.graph))
+    else:
+        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph))
+
+    nb = max(1, args.distinct_batches)
+    idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
+    idx_dev = [t.to(device) for t in idxs]
+    lab_dev = [t.to(device) for t in labs]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    timer = None
+    if not args.graph:
+        timer = KernelTimer()
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__()
+    measured_in = "timed region"
+    if timer is None:
+        # graph replay cannot carry events: time the same launches in an eager pass of the same K steps
+        eager = eng
+        eager.use_graph = False
+        with KernelTimer() as timer:
+            for i in range(args.steps):
+                eager.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
+        eager.use_graph = True
+        measured_in = "separate eager pass of the same K steps (graph replay cannot carry events)"
+    summ = timer.summary()
+    final_loss = float(loss.item())
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel family (the fp32 MFMA GEMM) -------------------------------
+    kernels = []
+    gemm_flop = gemm_us = 0.0
+    gather = None
+    per_step = {}
+    for (name, shape), a in sorted(summ.items(), key=lambda kv: -kv[1]["total_us"]):
+        per_step[name] = per_step.get(name, 0.0) + a["total_us"] / args.steps
+        ent = {"entry": name, "shape": shape, "launches": a["n"], "avg_us": round(a["avg_us"], 2)}
+        if a["unit"] == "flop":
+            ent["tflops"] = round(a["work"] / a["avg_us"] / 1e6, 2)
+            ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
+            gemm_flop += a["work"] * a["n"]
+            gemm_us += a["total_us"]
+        elif a["unit"] == "byte":
+            ent["gbs"] = round(a["work"] / a["avg_us"] / 1e3, 1)
+            ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e3 / HBM_PEAK_GBS, 4)
+            gather = (a, ent)
+        kernels.append(ent)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("dominant_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if gemm_us > 0:
+        ach = gemm_flop / gemm_us / 1e6
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all MLP GEMM launches of a step",
+                    "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_flop_per_step": gemm_flop / args.steps, "us_per_step": round(gemm_us / args.steps, 1),
+                    "measured_in": measured_in}
+    else:
+        a, ent = gather
+        roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ent["frac_of_peak"], "traffic": traffic, "measured_in": measured_in}
+    roofline_hbm = None
+    if gather is not None:
+        a, ent = gather
+        roofline_hbm = {"bound": "hbm", "kernel": "gather_fused_kernel (K1)", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ent["frac_of_peak"], "algorithmic_bytes_per_launch": a["work"],
+                        "avg_us": ent["avg_us"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        cpu = cpu_baseline(args, rec, hidden, idxs, labs)
+
+    if rank == 0:
+        total = args.batch * world * args.steps
+        out = {
+            "metric": "train samples/sec (node) DeepFM Criteo_x1 bs=4096" if args.model == "deepfm"
+                      else f"train samples/sec (node) {args.model}",
+            "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} training step, Criteo_x1-shaped: 39 fields (13 small-vocab + 26 "
+                                   f"log-spaced 10..1e6), embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
+                       "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
+                       "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
+                       "total_table_rows": sum(vocab), "hip_graph": bool(args.graph),
+                       "parallelism": "single GPU" if world == 1 else f"dp{world} + row-sharded tables (RCCL all-to-all)"},
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
+            "kernel_us_per_step": {k: round(v, 1) for k, v in per_step.items()},
+            "kernels": kernels[:12], "final_loss": final_loss,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -187,6 +187,23 @@ struct ReduceArgs {
 };
 
 template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+
+constexpr int RU = 8;   // gradient rows in flight per lane group
+
+template <int VEC>
 __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
     const int f = blockIdx.y;
     const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
@@ -201,34 +218,44 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     float acc1 = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const int src = ss[i];
-        float g[VEC];
+    for (int i = i0; i < i1; i += RU) {
+        int src[RU];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) g[e] = 0.f;
-        if (a.gout) {
-            if constexpr (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(a.gout + (long long)src * d + co);
-                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
-            } else g[0] = a.gout[(long long)src * d + co];
+        for (int u = 0; u < RU; ++u) src[u] = (i + u < i1) ? ss[i + u] : -1;
+        float g[RU][VEC], g1[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) g[u][e] = 0.f;
+            g1[u] = 0.f;
+            if (src[u] >= 0) {
+                const int b = src[u] / a.Fdiv;
+                if (a.gout) ldv<VEC>(a.gout + (long long)src[u] * d + co, g[u]);
+                if (a.dfm) {
+                    const float s = a.dfm[b];
+                    float sv[VEC], ev[VEC];
+                    ldv<VEC>(a.S + (long long)b * d + co, sv);
+                    ldv<VEC>(a.emb + (long long)src[u] * d + co, ev);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[u][e] += s * (sv[e] - ev[e]);
+                }
+                if (cc == 0) {
+                    if (a.g1src) g1[u] += a.g1src[src[u]];
+                    if (a.dlr) g1[u] += a.dlr[b];
+                }
+            }
         }
-        const int b = src / a.Fdiv;
-        if (a.dfm) {
-            const float s = a.dfm[b];
+        // adds stay in ascending sorted order (= ascending sample order): fixed summation order
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                g[e] += s * (a.S[(long long)b * d + co + e] - a.emb[(long long)src * d + co + e]);
-        }
+        for (int u = 0; u < RU; ++u) {
+            if (src[u] >= 0) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += g[e];
-        if (cc == 0) {
-            if (a.g1src) acc1 += a.g1src[src];
-            if (a.dlr) acc1 += a.dlr[b];
+                for (int e = 0; e < VEC; ++e) acc[e] += g[u][e];
+                acc1 += g1[u];
+            }
         }
     }
-    float* o = a.chunk_sum + ((long long)f * a.cap + c) * d + co;
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = acc[e];
+    stv<VEC>(a.chunk_sum + ((long long)f * a.cap + c) * d + co, acc);
     if (cc == 0 && a.chunk_sum1) a.chunk_sum1[(long long)f * a.cap + c] = acc1;
 }
 
@@ -249,14 +276,15 @@ __global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
         float acc1 = 0.f;
         for (int c = c0; c < c1; ++c) {
-            const float* p = a.chunk_sum + ((long long)f * a.cap + c) * d + co;
+            float p[VEC];
+            ldv<VEC>(a.chunk_sum + ((long long)f * a.cap + c) * d + co, p);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] += p[e];
             if (cc == 0 && a.chunk_sum1) acc1 += a.chunk_sum1[(long long)f * a.cap + c];
         }
-        float* o = a.rowgrad + ((long long)f * a.cap + u) * d + co;
+        stv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, acc);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { o[e] = acc[e]; nsq += acc[e] * acc[e]; }
+        for (int e = 0; e < VEC; ++e) nsq += acc[e] * acc[e];
         if (cc == 0 && a.rowgrad1) { a.rowgrad1[(long long)f * a.cap + u] = acc1; nsq += acc1 * acc1; }
     }
     const float tot = rs_block_sum<256>(nsq, red);
@@ -308,14 +336,17 @@ __global__ __launch_bounds__(256) void sparse_update_kernel(UpdateArgs a) {
     const float coef = a.scal ? a.scal[1] : 1.f;
     const int d = a.d, co = cc * VEC;
     if (a.table) {
-        const float* gp = a.rowgrad + ((long long)f * a.cap + u) * d + co;
+        const long long o = row * d + co;
+        float g[VEC], w[VEC], mm[VEC], vv[VEC];
+        ldv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, g);
+        ldv<VEC>(a.table + o, w);
+        if (a.m) ldv<VEC>(a.m + o, mm);
+        if (a.v) ldv<VEC>(a.v + o, vv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const long long o = row * d + co + e;
-            float w = a.table[o];
-            opt_update(a.opt, a.hyper, gp[e] * coef, w, a.m ? a.m + o : nullptr, a.v ? a.v + o : nullptr);
-            a.table[o] = w;
-        }
+        for (int e = 0; e < VEC; ++e) opt_update(a.opt, a.hyper, g[e] * coef, w[e], a.m ? &mm[e] : nullptr, a.v ? &vv[e] : nullptr);
+        stv<VEC>(a.table + o, w);
+        if (a.m) stv<VEC>(a.m + o, mm);
+        if (a.v) stv<VEC>(a.v + o, vv);
     }
     if (cc == 0 && a.table1) {
         float w = a.table1[row];
@@ -336,9 +367,9 @@ __global__ __launch_bounds__(256) void scatter_rowgrad_kernel(UpdateArgs a) {
     const long long row = a.seg_row[(long long)f * a.cap + u];
     const int d = a.d, co = cc * VEC;
     if (a.table) {
-        const float* gp = a.rowgrad + ((long long)f * a.cap + u) * d + co;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) a.table[row * d + co + e] = gp[e];
+        float g[VEC];
+        ldv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, g);
+        stv<VEC>(a.table + row * d + co, g);
     }
     if (cc == 0 && a.table1) a.table1[row] = a.rowgrad1[(long long)f * a.cap + u];
 }

@@ -1,0 +1,88 @@
+"""Per-launch kernel timing with HIP events recorded on the launch stream.
+
+``KernelTimer`` wraps the single funnel through which every C-ABI entry point is called
+(``_lib.call``) and brackets the selected entry points with ``torch.cuda.Event`` pairs recorded on
+torch's current stream -- the stream the kernels are launched on.  Durations are read after a
+device synchronisation, so nothing is synchronised inside the measured region.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+
+import torch
+
+from . import _lib, ops
+
+
+def _gemm_key(args):
+    a_mc, b_nc, M, N, K = args[0], args[1], args[2], args[3], args[4]
+    return ("rs_gemm_f32", f"{'T' if a_mc else 'N'}{'N' if b_nc else 'T'} M={M} N={N} K={K}"), 2.0 * M * N * K, "flop"
+
+
+def _gather_key(args):
+    B, F, d = args[11], args[12], args[13]
+    has_table, has_t1 = args[3] is not None, args[4] is not None
+    emb_out, sum_out, lr_out, fm_out = args[6], args[7], args[9], args[10]
+    byts = B * F * 8
+    if has_table:
+        byts += B * F * d * 4
+    if has_t1:
+        byts += B * F * 4
+    if emb_out is not None:
+        byts += B * F * d * 4
+    if sum_out is not None:
+        byts += B * d * 4
+    byts += (4 * B if lr_out is not None else 0) + (4 * B if fm_out is not None else 0)
+    return ("rs_gather_lr_fm_fwd", f"B={B} F={F} d={d}"), float(byts), "byte"
+
+
+KEYERS = {"rs_gemm_f32": _gemm_key, "rs_gather_lr_fm_fwd": _gather_key}
+
+
+class KernelTimer:
+    def __init__(self, names=("rs_gemm_f32", "rs_gather_lr_fm_fwd", "rs_sparse_bwd_sort", "rs_sparse_bwd_reduce",
+                              "rs_sparse_update", "rs_dense_update", "rs_colsum_f32", "rs_bce_head")):
+        self.names = set(names)
+        self.records = []          # (key, work, unit, start_event, end_event)
+
+    def __enter__(self):
+        self._orig = _lib.call
+        timer = self
+
+        def timed_call(name, *args):
+            if name not in timer.names:
+                return timer._orig(name, *args)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig(name, *args)
+            e.record()
+            if name in KEYERS:
+                key, work, unit = KEYERS[name](args)
+            else:
+                key, work, unit = (name, ""), 0.0, ""
+            timer.records.append((key, work, unit, s, e))
+            return r
+
+        _lib.call = timed_call
+        ops.call = timed_call
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call = self._orig
+        ops.call = self._orig
+        return False
+
+    def summary(self):
+        """{(entry point, shape): dict(n, avg_us, total_us, work_per_launch, unit)} after a device sync."""
+        torch.cuda.synchronize()
+        agg = defaultdict(lambda: {"n": 0, "total_us": 0.0, "work": 0.0, "unit": ""})
+        for key, work, unit, s, e in self.records:
+            a = agg[key]
+            a["n"] += 1
+            a["total_us"] += s.elapsed_time(e) * 1e3
+            a["work"] = work
+            a["unit"] = unit
+        for a in agg.values():
+            a["avg_us"] = a["total_us"] / max(a["n"], 1)
+        return dict(agg)
