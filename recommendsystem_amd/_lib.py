@@ -31,7 +31,7 @@ _SIGS = {
     # gemm.hip
     "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
                     I, I, c_f32p, SZ, c_stream],
-    "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, SZ, c_stream],
+    "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, SZ, c_stream],
     # sparse.hip
     "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
@@ -43,8 +43,12 @@ _SIGS = {
     "rs_sumsq_partials": [c_f32p, L, c_f32p, I, c_stream],
     "rs_clip_coef": [c_f32p, I, F, c_f32p, c_stream],
     "rs_opt_prepare": [c_i64p, c_f32p, c_stream],
+    "rs_clip_and_prepare": [c_f32p, I, F, c_f32p, c_i64p, c_f32p, c_stream],
     # elementwise.hip
-    "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F, c_stream],
+    "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F,
+                    c_f32p, c_f32p, I, c_f32p, c_f32p, c_stream],
+    "rs_rowdot_fwd": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_stream],
+    "rs_rowdot_bwd_dx": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_act_fwd": [c_f32p, c_f32p, L, I, c_f32p, c_stream],
     "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
     "rs_bn_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, I, F, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
@@ -69,6 +73,7 @@ _PLAIN = {
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_sort_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
+    "rs_sparse_window": (I, [I]),
     "rs_act_bwd_num_partials": (I, [L]),
 }
 

@@ -7,14 +7,20 @@ namespace {
 // loss = mean(-(y*max(log p,-100) + (1-y)*max(log1p(-p),-100)))    [F.binary_cross_entropy,
 // model/utils/BaseModel.py:75,145 applied to sigmoid outputs as model/LR/LR.py:32 does]
 // dz = dloss/dlogit following autograd's two steps (BCE backward then sigmoid backward).
+// Optional extras for the fused step (all sums in fixed order, one workgroup):
+//   sum_dz_out[0]   = sum_b dz[b]                     (gradient of a bias added to the logit)
+//   dzh_out[b]      = dz[b] * act'(hlast[b])          (gradient at the pre-activation of a 1-wide last
+//   sum_dzh_out[0]  = sum_b dzh_out[b]                 layer whose output hlast is one of the parts)
 __global__ __launch_bounds__(1024) void bce_head_kernel(const float* __restrict__ z0, const float* __restrict__ z1,
                                                         const float* __restrict__ z2, const float* __restrict__ yf,
                                                         const int64_t* __restrict__ yi, int B,
                                                         float* __restrict__ logit_out, float* __restrict__ prob_out,
                                                         float* __restrict__ loss_out, float* __restrict__ dz_out,
-                                                        float grad_scale) {
+                                                        float grad_scale, float* __restrict__ sum_dz_out,
+                                                        const float* __restrict__ hlast, int act_last,
+                                                        float* __restrict__ dzh_out, float* __restrict__ sum_dzh_out) {
     __shared__ float red[16];
-    float s = 0.f;
+    float s = 0.f, sdz = 0.f, sdzh = 0.f;
     const float invB = 1.f / (float)B;
     for (int b = threadIdx.x; b < B; b += 1024) {
         float z = z0[b];
@@ -26,13 +32,63 @@ __global__ __launch_bounds__(1024) void bce_head_kernel(const float* __restrict_
         s += -(y * lp + (1.f - y) * l1p);
         if (logit_out) logit_out[b] = z;
         if (prob_out) prob_out[b] = p;
-        if (dz_out) {
-            const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * invB * grad_scale;
-            dz_out[b] = gp * ((1.f - p) * p);
+        const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * invB * grad_scale;
+        const float dz = gp * ((1.f - p) * p);
+        if (dz_out) dz_out[b] = dz;
+        sdz += dz;
+        if (hlast) {
+            const float h = hlast[b];
+            const float dzh = dz * rs_act_grad(act_last, h, h, 0.f);
+            if (dzh_out) dzh_out[b] = dzh;
+            sdzh += dzh;
         }
     }
     const float tot = rs_block_sum<1024>(s, red);
     if (threadIdx.x == 0 && loss_out) loss_out[0] = tot * invB;
+    if (sum_dz_out) {
+        const float t = rs_block_sum<1024>(sdz, red);
+        if (threadIdx.x == 0) sum_dz_out[0] = t;
+    }
+    if (sum_dzh_out) {
+        const float t = rs_block_sum<1024>(sdzh, red);
+        if (threadIdx.x == 0) sum_dzh_out[0] = t;
+    }
+}
+
+// ---- 1-wide linear layer (the MLP head, model/DeepFM/DeepFM.py:35): h[m] = act(x[m,:].w + b) -----
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ X, int M, int K,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int act, float* __restrict__ h) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = X + (long long)m * K;
+    float s = 0.f;
+    if ((K & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(x + k);
+            const float4 b = *reinterpret_cast<const float4*>(w + k);
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) s = fmaf(x[k], w[k], s);
+    }
+    s = rs_wave_sum(s);
+    if (lane == 0) h[m] = rs_act(act, s + (bias ? bias[0] : 0.f), 0.f);
+}
+
+// dX[m,k] = dz[m] * w[k] * act'_prev(X[m,k])   (X is the previous block's output; mul_act = its activation)
+__global__ __launch_bounds__(256) void rowdot_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                            const float* __restrict__ X, int mul_act, int M, int K,
+                                                            float* __restrict__ dX) {
+    const long long total = (long long)M * K;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int m = (int)(i / K), k = (int)(i % K);
+        float v = dz[m] * w[k];
+        if (mul_act) { const float hh = X[i]; v *= rs_act_grad(mul_act, hh, hh, 0.f); }
+        dX[i] = v;
+    }
 }
 
 // dst[b] = act(z[b])-style pointwise helpers on vectors -------------------------------------
@@ -254,14 +310,44 @@ extern "C" {
 
 // Loss head of the training step; any of logit_out/prob_out/loss_out/dz_out may be null.
 // Labels come either as float (labels_f32) or int64 (labels_i64); exactly one must be non-null.
+// sum_dz_out / hlast / act_last / dzh_out / sum_dzh_out: optional fused by-products (see kernel).
 int rs_bce_head(const float* z0, const float* z1, const float* z2, const float* labels_f32,
                 const int64_t* labels_i64, int B, float* logit_out, float* prob_out, float* loss_out,
-                float* dz_out, float grad_scale, hipStream_t stream) {
+                float* dz_out, float grad_scale, float* sum_dz_out, const float* hlast, int act_last, float* dzh_out,
+                float* sum_dzh_out, hipStream_t stream) {
     RS_CHECK_ARG(B > 0 && z0, "rs_bce_head: empty batch or null logits");
     RS_CHECK_ARG((labels_f32 != nullptr) != (labels_i64 != nullptr), "rs_bce_head: pass exactly one label array");
+    RS_CHECK_ARG(hlast || !(dzh_out || sum_dzh_out), "rs_bce_head: dzh outputs need hlast");
+    RS_CHECK_ARG(act_last >= RS_ACT_NONE && act_last <= RS_ACT_LEAKYRELU, "rs_bce_head: bad act_last");
     hipLaunchKernelGGL(bce_head_kernel, dim3(1), dim3(1024), 0, stream, z0, z1, z2, labels_f32, labels_i64, B,
-                       logit_out, prob_out, loss_out, dz_out, grad_scale);
+                       logit_out, prob_out, loss_out, dz_out, grad_scale, sum_dz_out, hlast, act_last, dzh_out,
+                       sum_dzh_out);
     RS_CHECK_LAUNCH("rs_bce_head");
+    return RS_OK;
+}
+
+// h[m] = act(X[m,:] . w + bias[0]): forward of a 1-wide linear layer (one wave per row).
+int rs_rowdot_fwd(const float* X, int M, int K, const float* w, const float* bias, int act, float* h,
+                  hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && K > 0, "rs_rowdot_fwd: bad sizes");
+    if (M == 0) return RS_OK;
+    RS_CHECK_ARG(X && w && h, "rs_rowdot_fwd: null argument");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_rowdot_fwd: activation %d not fusable", act);
+    RS_CHECK_ARG(((K & 3) != 0) || ((((uintptr_t)X | (uintptr_t)w) & 15) == 0), "rs_rowdot_fwd: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(rs_cdiv(M, 4)), dim3(256), 0, stream, X, M, K, w, bias, act, h);
+    RS_CHECK_LAUNCH("rs_rowdot_fwd");
+    return RS_OK;
+}
+
+// dX[m,k] = dz[m] * w[k] * act'(X[m,k])  (mul_act = 0: no activation factor)
+int rs_rowdot_bwd_dx(const float* dz, const float* w, const float* X, int mul_act, int M, int K, float* dX,
+                     hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && K > 0, "rs_rowdot_bwd_dx: bad sizes");
+    if (M == 0) return RS_OK;
+    RS_CHECK_ARG(dz && w && dX && (X || !mul_act), "rs_rowdot_bwd_dx: null argument");
+    hipLaunchKernelGGL(rowdot_bwd_dx_kernel, dim3(flat_blocks((long long)M * K)), dim3(256), 0, stream, dz, w, X, mul_act,
+                       M, K, dX);
+    RS_CHECK_LAUNCH("rs_rowdot_bwd_dx");
     return RS_OK;
 }
 

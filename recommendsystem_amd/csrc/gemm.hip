@@ -527,39 +527,71 @@ int dispatch(const GemmArgs& g, bool va, bool vb, int tile, hipStream_t s) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// column sums: out[n] = sum_m X[m, n].  Stage 1: one workgroup per (64 columns, 256 rows) writes a
-// partial row; stage 2 adds the partial rows in order.  Fixed summation order.
-constexpr int CS_ROWS = 256;
+// column sums: out[n] = sum_m scale[m] * X[m, n] (scale optional).  Stage 1: one workgroup per
+// (256 columns, 64 rows): every lane keeps 16 independent 16-byte loads in flight; the four waves'
+// sums meet in LDS.  Stage 2 adds the per-row-block partials in order.  Fixed summation order.
+constexpr int CS_ROWS = 64;
+template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ X, int M, int N, int ld,
+                                                            const float* __restrict__ scale,
                                                             float* __restrict__ part_out) {
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + c;
+    __shared__ float part[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int mbeg = blockIdx.y * CS_ROWS, mend = min(M, mbeg + CS_ROWS);
-    // 8 independent accumulators: the loads of one pass are all in flight together
-    float s[8];
+    const int n0 = blockIdx.x * 256;
+    if constexpr (VEC) {
+        const int n = n0 + lane * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            float4 v[16];
+            float sc[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = 0.f;
-    if (n < N) {
-        for (int m = mbeg + w; m < mend; m += 32) {
+            for (int u = 0; u < 16; ++u) {
+                const int m = mbeg + w + u * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                sc[u] = 1.f;
+                if (m < mend) {
+                    v[u] = *reinterpret_cast<const float4*>(X + (long long)m * ld + n);
+                    if (scale) sc[u] = scale[m];
+                }
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int mm = m + u * 4;
-                if (mm < mend) s[u] += X[(long long)mm * ld + n];
+            for (int u = 0; u < 16; ++u) {
+                acc.x = fmaf(sc[u], v[u].x, acc.x); acc.y = fmaf(sc[u], v[u].y, acc.y);
+                acc.z = fmaf(sc[u], v[u].z, acc.z); acc.w = fmaf(sc[u], v[u].w, acc.w);
             }
         }
+        *reinterpret_cast<float4*>(&part[w][lane * 4]) = acc;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = n0 + c * 64 + lane;
+            float acc = 0.f;
+            if (n < N)
+                for (int m = mbeg + w; m < mend; m += 4) acc = fmaf(scale ? scale[m] : 1.f, X[(long long)m * ld + n], acc);
+            part[w][c * 64 + lane] = acc;
+        }
     }
-    part[w][c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (w == 0 && n < N) part_out[(long long)blockIdx.y * N + n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    const int n = n0 + threadIdx.x;
+    if (n < N) {
+        const int t = threadIdx.x;
+        part_out[(long long)blockIdx.y * N + n] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    }
 }
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int chunks, int N,
                                                             float* __restrict__ out) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long long)c * N + n];
-    out[n] = s;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int c = 0; c < chunks; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + u < chunks) s[u] += part[(long long)(c + u) * N + n];
+    }
+    out[n] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 }  // namespace
@@ -630,10 +662,11 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
 
 size_t rs_colsum_workspace_bytes(int M, int N) { return (size_t)rs_cdiv(M, CS_ROWS) * N * sizeof(float); }
 
-// out[n] = sum_m X[m, n]  (bias gradient of nn.Linear, model/utils/Layers.py:42; also the
-// dgamma/dbeta sums of LayerNorm).  workspace: rs_colsum_workspace_bytes(M, N).
-int rs_colsum_f32(const float* X, int M, int N, int ld, float* out, float* workspace, size_t workspace_bytes,
-                  hipStream_t stream) {
+// out[n] = sum_m scale[m] * X[m, n]; scale may be null (plain column sums: the bias gradient of
+// nn.Linear, model/utils/Layers.py:42, and the dgamma/dbeta sums of LayerNorm).  With a scale vector
+// it is the weight gradient of a 1-wide layer.  workspace: rs_colsum_workspace_bytes(M, N).
+int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, float* out, float* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "rs_colsum_f32: bad sizes");
     if (N == 0) return RS_OK;
     RS_CHECK_ARG(out, "rs_colsum_f32: null output");
@@ -644,7 +677,10 @@ int rs_colsum_f32(const float* X, int M, int N, int ld, float* out, float* works
     RS_CHECK_ARG(X, "rs_colsum_f32: null input");
     RS_CHECK_ARG(workspace && workspace_bytes >= rs_colsum_workspace_bytes(M, N), "rs_colsum_f32: workspace too small");
     const int chunks = rs_cdiv(M, CS_ROWS);
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(rs_cdiv(N, 64), chunks), dim3(256), 0, stream, X, M, N, ld, workspace);
+    const bool vec = aligned16(X) && ld % 4 == 0 && N % 4 == 0;
+    dim3 grid(rs_cdiv(N, 256), chunks);
+    if (vec) hipLaunchKernelGGL(colsum_stage1_kernel<true>, grid, dim3(256), 0, stream, X, M, N, ld, scale, workspace);
+    else hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, stream, X, M, N, ld, scale, workspace);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 256)), dim3(256), 0, stream, workspace, chunks, N, out);
     RS_CHECK_LAUNCH("rs_colsum_f32");
     return RS_OK;

@@ -23,6 +23,24 @@ namespace {
 
 constexpr int SORT_THREADS = 1024;
 
+// int32 scratch layout shared by every kernel of this file ("plan"), capacity `cap` entries per field:
+//   sorted_src [F,cap] | entry_chunk [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
+//   seg_first_chunk [F,cap+1] | counts [F,4]
+struct PlanView {
+    int* sorted_src; int* entry_chunk; int* chunk_start; int* seg_row; int* seg_first_chunk; int* counts;
+};
+inline PlanView carve_plan(int* plan, int F, int cap) {
+    PlanView v;
+    int* p = plan;
+    v.sorted_src = p; p += (size_t)F * cap;
+    v.entry_chunk = p; p += (size_t)F * cap;
+    v.chunk_start = p; p += (size_t)F * (cap + 1);
+    v.seg_row = p; p += (size_t)F * cap;
+    v.seg_first_chunk = p; p += (size_t)F * (cap + 1);
+    v.counts = p;
+    return v;
+}
+
 struct SortArgs {
     const int64_t* keys;      // index storage (int64, as the reference's .long() batches)
     const int* sub_off;       // [nsrc*F] start of sub-list (s, f) inside keys
@@ -33,6 +51,7 @@ struct SortArgs {
     const int64_t* vocab;     // [F]
     const int64_t* row_offset;// [F]
     int* sorted_src;          // [F, cap]   gradient-row index of the i-th entry in key order
+    int* entry_chunk;         // [F, cap]   chunk of the i-th entry in key order (-1: padding entry)
     int* chunk_start;         // [F, cap+1] first sorted position of each chunk (+ sentinel)
     int* seg_row;             // [F, cap]   stacked-table row of each segment
     int* seg_first_chunk;     // [F, cap+1] first chunk of each segment (+ sentinel)
@@ -141,6 +160,7 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
     const int n_seg = tot & 0xFFFF, n_chunk = tot >> 16;
     int seg = (ex & 0xFFFF), chk = (ex >> 16);
     int* sorted_src = a.sorted_src + (long long)f * a.cap;
+    int* entry_chunk = a.entry_chunk + (long long)f * a.cap;
     int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
     int* seg_row = a.seg_row + (long long)f * a.cap;
     int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
@@ -156,6 +176,7 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
                 ++seg;
             }
             if (flags[j] & 2) { chunk_start[chk] = i; ++chk; }
+            entry_chunk[i] = ((unsigned)(it[j] >> 32) == 0u) ? -1 : chk - 1;
         }
     }
     if (t == 0) {
@@ -168,9 +189,9 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
 
 // -------------------------------------------------------------------------------------------
 struct ReduceArgs {
-    const int* sorted_src; const int* chunk_start; const int* seg_row; const int* seg_first_chunk;
-    const int* counts;
-    int F, cap, d, C;            // C lanes per chunk/segment (d/4 or d)
+    const int* sorted_src; const int* entry_chunk; const int* chunk_start; const int* seg_row;
+    const int* seg_first_chunk; const int* counts;
+    int F, cap, d, C, L;         // C lanes per entry/segment (d/4 or d); L entries per wave window
     // gradient sources
     const float* gout;           // [*, d] gradient rows, indexed by sorted_src (or null)
     const float* g1src;          // [*]    1-dim gradient per gradient row (or null)
@@ -201,62 +222,64 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
     else *p = v[0];
 }
 
-constexpr int RU = 8;   // gradient rows in flight per lane group
+constexpr int RU = 8;   // chunk sums in flight per lane group (segment_finalize)
 
+// One wave per window of L consecutive sorted entries (L*C <= 64 lanes): every entry's gradient row is
+// loaded at once (C lanes per entry), then a segmented inclusive scan over the entries -- a fixed
+// shuffle tree keyed by the chunk id -- leaves each chunk's sum in its last entry.  Chunks never
+// cross a window (chunk heads fall on every multiple of L), so no carries leave the wave.
 template <int VEC>
 __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
     const int f = blockIdx.y;
-    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
-    const int gpb = 256 / a.C;
-    const int c = blockIdx.x * gpb + grp;
-    if (grp >= gpb || c >= a.counts[f * 4 + 1]) return;
-    const int* cs = a.chunk_start + (long long)f * (a.cap + 1);
-    const int* ss = a.sorted_src + (long long)f * a.cap;
-    const int i0 = cs[c], i1 = cs[c + 1];
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = a.counts[f * 4 + 0];
+    if (w * a.L >= n) return;                              // wave-uniform
+    const int e = lane / a.C, cc = lane - e * a.C;
+    const int i = w * a.L + e;
+    const bool valid = (e < a.L) && (i < n);
     const int d = a.d, co = cc * VEC;
-    float acc[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-    float acc1 = 0.f;
-    for (int i = i0; i < i1; i += RU) {
-        int src[RU];
-#pragma unroll
-        for (int u = 0; u < RU; ++u) src[u] = (i + u < i1) ? ss[i + u] : -1;
-        float g[RU][VEC], g1[RU];
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) g[u][e] = 0.f;
-            g1[u] = 0.f;
-            if (src[u] >= 0) {
-                const int b = src[u] / a.Fdiv;
-                if (a.gout) ldv<VEC>(a.gout + (long long)src[u] * d + co, g[u]);
-                if (a.dfm) {
-                    const float s = a.dfm[b];
-                    float sv[VEC], ev[VEC];
-                    ldv<VEC>(a.S + (long long)b * d + co, sv);
-                    ldv<VEC>(a.emb + (long long)src[u] * d + co, ev);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) g[u][e] += s * (sv[e] - ev[e]);
-                }
-                if (cc == 0) {
-                    if (a.g1src) g1[u] += a.g1src[src[u]];
-                    if (a.dlr) g1[u] += a.dlr[b];
-                }
-            }
-        }
-        // adds stay in ascending sorted order (= ascending sample order): fixed summation order
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            if (src[u] >= 0) {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += g[u][e];
-                acc1 += g1[u];
-            }
-        }
+    int cid = -1, src = 0;
+    if (valid) {
+        cid = a.entry_chunk[(long long)f * a.cap + i];
+        src = a.sorted_src[(long long)f * a.cap + i];
     }
-    stv<VEC>(a.chunk_sum + ((long long)f * a.cap + c) * d + co, acc);
-    if (cc == 0 && a.chunk_sum1) a.chunk_sum1[(long long)f * a.cap + c] = acc1;
+    float g[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) g[k] = 0.f;
+    float g1 = 0.f;
+    if (cid >= 0) {
+        const int b = src / a.Fdiv;
+        if (a.gout) ldv<VEC>(a.gout + (long long)src * d + co, g);
+        if (a.dfm) {
+            const float sdf = a.dfm[b];
+            float sv[VEC], ev[VEC];
+            ldv<VEC>(a.S + (long long)b * d + co, sv);
+            ldv<VEC>(a.emb + (long long)src * d + co, ev);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g[k] += sdf * (sv[k] - ev[k]);
+        }
+        if (a.g1src) g1 += a.g1src[src];
+        if (a.dlr) g1 += a.dlr[b];
+    }
+    for (int o = 1; o < a.L; o <<= 1) {
+        const int delta = o * a.C;
+        const int ucid = __shfl_up(cid, delta, 64);
+        const bool take = (e >= o) && (cid >= 0) && (ucid == cid);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float up = __shfl_up(g[k], delta, 64);
+            if (take) g[k] += up;
+        }
+        const float up1 = __shfl_up(g1, delta, 64);
+        if (take) g1 += up1;
+    }
+    const int ncid = __shfl_down(cid, a.C, 64);
+    const bool last = (cid >= 0) && (e == a.L - 1 || i + 1 >= n || ncid != cid);
+    if (last) {
+        stv<VEC>(a.chunk_sum + ((long long)f * a.cap + cid) * d + co, g);
+        if (cc == 0 && a.chunk_sum1) a.chunk_sum1[(long long)f * a.cap + cid] = g1;
+    }
 }
 
 template <int VEC>
@@ -275,12 +298,26 @@ __global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
         float acc1 = 0.f;
-        for (int c = c0; c < c1; ++c) {
-            float p[VEC];
-            ldv<VEC>(a.chunk_sum + ((long long)f * a.cap + c) * d + co, p);
+        for (int c = c0; c < c1; c += RU) {
+            float p[RU][VEC], p1[RU];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += p[e];
-            if (cc == 0 && a.chunk_sum1) acc1 += a.chunk_sum1[(long long)f * a.cap + c];
+            for (int r = 0; r < RU; ++r) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) p[r][e] = 0.f;
+                p1[r] = 0.f;
+                if (c + r < c1) {
+                    ldv<VEC>(a.chunk_sum + ((long long)f * a.cap + c + r) * d + co, p[r]);
+                    if (cc == 0 && a.chunk_sum1) p1[r] = a.chunk_sum1[(long long)f * a.cap + c + r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RU; ++r) {          // chunk order: fixed summation order
+                if (c + r < c1) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += p[r][e];
+                    acc1 += p1[r];
+                }
+            }
         }
         stv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, acc);
 #pragma unroll
@@ -426,10 +463,40 @@ __global__ void opt_prepare_kernel(long long* step, float* hyper) {
     }
 }
 
+// clip_coef_kernel and opt_prepare_kernel in one launch
+__global__ __launch_bounds__(256) void clip_prepare_kernel(const float* __restrict__ partials, int n, float max_norm,
+                                                           float* __restrict__ scal, long long* step, float* hyper) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    const float tot = rs_block_sum<256>(s, red);
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(tot);
+        scal[0] = nrm;
+        float c = max_norm / (nrm + 1e-6f);
+        scal[1] = (max_norm > 0.f && c < 1.f) ? c : 1.f;
+        const long long t = *step + 1;
+        *step = t;
+        const double b1 = (double)hyper[1], b2 = (double)hyper[2];
+        const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+        hyper[5] = (float)((double)hyper[0] / bc1);
+        hyper[6] = (float)sqrt(bc2);
+    }
+}
+
 int lanes_for(int d, int* VEC, int* C) {
-    if (d % 4 == 0 && d / 4 <= 256) { *VEC = 4; *C = d / 4; return 0; }
-    if (d <= 256) { *VEC = 1; *C = d; return 0; }
+    if (d % 4 == 0 && d / 4 <= 64) { *VEC = 4; *C = d / 4; return 0; }
+    if (d <= 64) { *VEC = 1; *C = d; return 0; }
     return -1;
+}
+
+// entries per wave window for embedding_dim d: the largest power of two L with L*C <= 64
+int window_for(int d) {
+    int VEC, C;
+    if (lanes_for(d, &VEC, &C) != 0) return -1;
+    int L = 1;
+    while (L * 2 * C <= 64) L *= 2;
+    return L;
 }
 
 }  // namespace
@@ -437,8 +504,9 @@ int lanes_for(int d, int* VEC, int* C) {
 extern "C" {
 
 // Bytes of int32 scratch per field-sort output set with capacity `cap` entries per field:
-//   sorted_src [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] | seg_first_chunk [F,cap+1] | counts [F,4]
-size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (4 * (size_t)cap + 2 + 4); }
+//   sorted_src [F,cap] | entry_chunk [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
+//   seg_first_chunk [F,cap+1] | counts [F,4]
+size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (5 * (size_t)cap + 2 + 4); }
 
 int rs_sort_max_entries(void) { return SORT_THREADS * 16; }
 
@@ -456,12 +524,9 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     SortArgs a;
     a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
     a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
-    int* p = plan;
-    a.sorted_src = p; p += (size_t)F * cap;
-    a.chunk_start = p; p += (size_t)F * (cap + 1);
-    a.seg_row = p; p += (size_t)F * cap;
-    a.seg_first_chunk = p; p += (size_t)F * (cap + 1);
-    a.counts = p;
+    const PlanView pv = carve_plan(plan, F, cap);
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.chunk_start = pv.chunk_start;
+    a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk; a.counts = pv.counts;
     int items = 1;
     while (items * SORT_THREADS < max_entries) items <<= 1;
     if (items < 4) items = 4;
@@ -488,12 +553,9 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
 }
 
 static int fill_reduce(ReduceArgs& a, const int* plan, int F, int cap, int d, int* VEC) {
-    const int* p = plan;
-    a.sorted_src = p; p += (size_t)F * cap;
-    a.chunk_start = p; p += (size_t)F * (cap + 1);
-    a.seg_row = p; p += (size_t)F * cap;
-    a.seg_first_chunk = p; p += (size_t)F * (cap + 1);
-    a.counts = p;
+    const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.chunk_start = pv.chunk_start;
+    a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk; a.counts = pv.counts;
     a.F = F; a.cap = cap; a.d = d;
     return lanes_for(d, VEC, &a.C);
 }
@@ -508,6 +570,8 @@ int rs_sparse_bwd_num_partials(int F, int cap, int d) {
 // Segmented reduction of gradient rows into one row gradient per touched table row, plus
 // per-workgroup ||g||^2 partials.  Gradient of entry with gradient-row index r (sample b = r/Fdiv):
 //   g = gout[r, :] (if gout) + dfm[b] * (S[b, :] - emb[r, :]) (if dfm);  1-dim: g1src[r] + dlr[b].
+int rs_sparse_window(int d) { return window_for(d); }
+
 int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                          const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                          float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1,
@@ -522,12 +586,14 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
     a.gout = gout; a.g1src = g1src; a.dfm = dfm; a.S = S; a.emb = emb; a.dlr = dlr; a.Fdiv = Fdiv;
     a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
     a.norm_partials = norm_partials;
+    a.L = window_for(d);       // the sort must have been run with the same L (rs_sparse_window(d))
     dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
+    dim3 wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F);
     if (VEC == 4) {
-        hipLaunchKernelGGL(chunk_reduce_kernel<4>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL(chunk_reduce_kernel<4>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_kernel<4>, grid, block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL(chunk_reduce_kernel<1>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL(chunk_reduce_kernel<1>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_kernel<1>, grid, block, 0, stream, a);
     }
     RS_CHECK_LAUNCH("rs_sparse_bwd_reduce");
@@ -535,10 +601,9 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
 }
 
 static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, int* VEC) {
-    const int* p = plan;
-    p += (size_t)F * cap; p += (size_t)F * (cap + 1);
-    a.seg_row = p; p += (size_t)F * cap; p += (size_t)F * (cap + 1);
-    a.counts = p;
+    const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
+    a.seg_row = pv.seg_row;
+    a.counts = pv.counts;
     a.F = F; a.cap = cap; a.d = d;
     return lanes_for(d, VEC, &a.C);
 }
@@ -614,6 +679,15 @@ int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, hipS
     RS_CHECK_ARG(partials && scal && n >= 0, "rs_clip_coef: bad arguments");
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partials, n, max_norm, scal);
     RS_CHECK_LAUNCH("rs_clip_coef");
+    return RS_OK;
+}
+
+// rs_clip_coef followed by rs_opt_prepare, as one launch.
+int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
+                        hipStream_t stream) {
+    RS_CHECK_ARG(partials && scal && step && hyper && n >= 0, "rs_clip_and_prepare: bad arguments");
+    hipLaunchKernelGGL(clip_prepare_kernel, dim3(1), dim3(256), 0, stream, partials, n, max_norm, scal, step, hyper);
+    RS_CHECK_LAUNCH("rs_clip_and_prepare");
     return RS_OK;
 }
 

@@ -191,23 +191,30 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     return out
 
 
-def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None) -> torch.Tensor:
+def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None, scale=None) -> torch.Tensor:
+    """out[n] = sum_m scale[m] * x[m, n] (scale optional)."""
     _chk(x, torch.float32, "x")
     M, N = x.shape
+    _chk(scale, torch.float32, "scale", (M,))
     if out is None:
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
     ws = ws or default_workspace(x.device)
     wbytes = _lib.lib().rs_colsum_workspace_bytes(M, N)
     wbuf = ws.get("colsum", max(wbytes // 4, 1))
-    call("rs_colsum_f32", ptr(x), M, N, N, ptr(out), ptr(wbuf), wbytes, stream())
+    call("rs_colsum_f32", ptr(x), M, N, N, ptr(scale), ptr(out), ptr(wbuf), wbytes, stream())
     return out
 
 
 # ---------------------------------------------------------------------------------------------
 # loss head
 # ---------------------------------------------------------------------------------------------
-def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, want_dz=True, grad_scale=1.0):
-    """loss = BCE(sigmoid(sum(parts)), labels) (mean); returns dict(loss, dz, logit, prob)."""
+def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, want_dz=True, grad_scale=1.0,
+             sum_dz_out=None, hlast=None, act_last=0, want_dzh=False, sum_dzh_out=None):
+    """loss = BCE(sigmoid(sum(parts)), labels) (mean); returns dict(loss, dz, logit, prob, dzh).
+
+    sum_dz_out: 1-element tensor receiving sum(dz) (gradient of a bias added to the logit).
+    hlast/act_last: output and activation of a 1-wide last layer that is one of the parts; then
+    dzh = dz * act'(hlast) is returned and sum_dzh_out (1 element) receives its sum."""
     parts = [p.reshape(-1) for p in parts if p is not None]
     B = parts[0].numel()
     for p in parts:
@@ -224,6 +231,7 @@ def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, wan
     else:
         raise RSError(f"bce_head: labels must be float32 or int64, got {labels.dtype}")
     _chk(labels, labels.dtype, "labels", (B,))
+    _chk(hlast, torch.float32, "hlast")
     out = {"loss": torch.empty(1, dtype=torch.float32, device=dev)}
     if want_logit:
         out["logit"] = torch.empty(B, dtype=torch.float32, device=dev)
@@ -231,9 +239,34 @@ def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, wan
         out["prob"] = torch.empty(B, dtype=torch.float32, device=dev)
     if want_dz:
         out["dz"] = torch.empty(B, dtype=torch.float32, device=dev)
+    if want_dzh:
+        out["dzh"] = torch.empty(B, dtype=torch.float32, device=dev)
     call("rs_bce_head", ptr(parts[0]), ptr(parts[1]), ptr(parts[2]), ptr(lf), ptr(li), B, ptr(out.get("logit")),
-         ptr(out.get("prob")), ptr(out["loss"]), ptr(out.get("dz")), float(grad_scale), stream())
+         ptr(out.get("prob")), ptr(out["loss"]), ptr(out.get("dz")), float(grad_scale), ptr(sum_dz_out),
+         ptr(hlast.reshape(-1) if hlast is not None else None), int(act_last), ptr(out.get("dzh")), ptr(sum_dzh_out),
+         stream())
     return out
+
+
+def rowdot_fwd(x: torch.Tensor, w: torch.Tensor, bias, act: int) -> torch.Tensor:
+    """h[m] = act(x[m, :] . w + bias): a 1-wide linear layer."""
+    _chk(x, torch.float32, "x")
+    M, K = x.shape
+    _chk(w, torch.float32, "w")
+    if w.numel() != K:
+        raise RSError("rowdot_fwd: weight length differs from the input width")
+    h = torch.empty(M, dtype=torch.float32, device=x.device)
+    call("rs_rowdot_fwd", ptr(x), M, K, ptr(w), ptr(bias), int(act), ptr(h), stream())
+    return h
+
+
+def rowdot_bwd_dx(dz: torch.Tensor, w: torch.Tensor, x: torch.Tensor, mul_act: int) -> torch.Tensor:
+    """dx[m, k] = dz[m] * w[k] * act'(x[m, k])."""
+    M, K = x.shape
+    _chk(dz, torch.float32, "dz", (M,))
+    dx = torch.empty_like(x)
+    call("rs_rowdot_bwd_dx", ptr(dz), ptr(w), ptr(x), int(mul_act), M, K, ptr(dx), stream())
+    return dx
 
 
 # ---------------------------------------------------------------------------------------------
@@ -245,7 +278,6 @@ class SparsePlan:
     cap = max entries per field.  Buffers are allocated once and reused every step.
     """
 
-    CHUNK = 32          # L: max sorted entries summed sequentially by one lane group
 
     def __init__(self, layout: FieldLayout, cap: int, d: int, with_lr: bool, device=None):
         h = _lib.lib()
@@ -257,6 +289,10 @@ class SparsePlan:
         if cap > h.rs_sort_max_entries():
             raise RSError(f"sparse backward: {cap} entries per field exceed the in-LDS sort limit "
                           f"{h.rs_sort_max_entries()}")
+        # entries per wave window of the segmented reduction (chunks are cut at its multiples)
+        self.CHUNK = h.rs_sparse_window(self.d)
+        if self.CHUNK <= 0:
+            raise RSError(f"sparse backward: unsupported embedding_dim {d}")
         self.plan = torch.zeros(h.rs_sort_plan_ints(self.F, self.cap), dtype=torch.int32, device=dev)
         self.chunk_sum = torch.empty((self.F, self.cap, self.d), dtype=torch.float32, device=dev)
         self.rowgrad = torch.empty((self.F, self.cap, self.d), dtype=torch.float32, device=dev)
@@ -269,11 +305,11 @@ class SparsePlan:
 
     # views into the plan (for tests / inspection)
     def counts(self):
-        off = self.F * (4 * self.cap + 2)
+        off = self.F * (5 * self.cap + 2)
         return self.plan[off:off + 4 * self.F].view(self.F, 4)
 
     def seg_rows(self):
-        off = self.F * self.cap + self.F * (self.cap + 1)
+        off = 2 * self.F * self.cap + self.F * (self.cap + 1)
         return self.plan[off:off + self.F * self.cap].view(self.F, self.cap)
 
     def columnar_lists(self, B: int):
@@ -331,6 +367,13 @@ def sumsq_partials(x: torch.Tensor, partials: torch.Tensor):
 
 def clip_coef(partials: torch.Tensor, max_norm: float, scal: torch.Tensor):
     call("rs_clip_coef", ptr(partials), partials.numel(), float(max_norm), ptr(scal), stream())
+
+
+def clip_and_prepare(partials: torch.Tensor, max_norm: float, scal: torch.Tensor, step: torch.Tensor,
+                     hyper: torch.Tensor):
+    """clip_coef + opt_prepare in one launch."""
+    call("rs_clip_and_prepare", ptr(partials), partials.numel(), float(max_norm), ptr(scal), ptr(step), ptr(hyper),
+         stream())
 
 
 def dense_update(w, g, m, v, opt: str, hyper, scal):

@@ -64,10 +64,10 @@ def test_row_sets_and_row_grads(B, vocabs, d):
     got = grad.cpu()
     mag = _dense_ref(idx, vocabs, gout.abs(), d)
     assert ((got - want).abs() <= 1e-6 * mag + 1e-30).all()
-    # rows touched fewer than CHUNK times are summed in the same order as torch CPU: bit-exact
+    # rows touched once or twice have a single possible summation order: bit-exact against torch CPU
     for f, v in enumerate(vocabs):
         cnt = torch.bincount(idx[f], minlength=v)
-        small = torch.nonzero((cnt > 0) & (cnt <= 1)).flatten()
+        small = torch.nonzero((cnt > 0) & (cnt <= 2)).flatten()
         small = small[small != 0] + layout.row_offsets[f]
         assert torch.equal(got[small], want[small])
     # gradient norm from the partials
@@ -99,7 +99,11 @@ def test_golden_table_grads():
     grad = torch.zeros(layout.total_rows, d, device=dev)
     plan.scatter_dense(grad=grad)
     want = np.concatenate([g[f"table_grad.{c}"] for c in cols], 0)
-    assert np.array_equal(grad.cpu().numpy(), want)        # tiny batch: same summation order => bit-exact
+    got = grad.cpu().numpy()
+    # same non-zero row set as the reference's dense gradient; values agree to fp32 reassociation
+    # (rows hit by up to two samples are bit-exact: a two-term sum has one order)
+    assert np.array_equal(np.abs(got).sum(1) != 0, np.abs(want).sum(1) != 0)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
 
 
 def test_fm_and_lr_terms_fused_in_reduce():
