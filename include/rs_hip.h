@@ -1,0 +1,156 @@
+/*
+ * librs_hip.so -- C-ABI of the MI355X (gfx950) CTR training hot path.
+ *
+ * The reference (HaochengY/RecommendSystem) is pure Python/PyTorch and has no FFI: the interface it
+ * exposes for this path is the nn.Module surface of model/utils/Layers.py as driven by
+ * model/utils/BaseModel.py.  Each entry point below therefore cites the reference lines whose
+ * arithmetic it replaces; the Python modules in recommendsystem_amd/ keep the reference's class
+ * names, constructor arguments and forward signatures and call these functions through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; fp32 data, int64 indices
+ *     (model/utils/Layers.py:147 `.long()`), int32 scratch;
+ *   - functions return 0 on success, a negative code on error (-1 argument/shape, -2 launch,
+ *     -3 workspace); rs_last_error_string() gives the message of the calling thread's last error;
+ *   - nothing is allocated, freed or synchronised inside: outputs and scratch are caller-owned, work is
+ *     enqueued on `stream` (safe under HIP graph capture);
+ *   - index batches are columnar: idx[f*B + b] is the index of field f in sample b, i.e. the
+ *     reference's dict of per-column (B,) tensors laid end to end;
+ *   - all per-field tables live in one stacked table [R, d]; row_offset[f] is field f's first row,
+ *     vocab[f] its row count; row 0 of every field is the padding row (padding_idx=0);
+ *   - activation codes: 0 none, 1 ReLU, 2 Tanh, 3 LeakyReLU(0.01), 4 PReLU;
+ *     optimizer codes: 0 SGD, 1 Adam, 2 AdamW, 3 Adagrad.
+ */
+#ifndef RS_HIP_H
+#define RS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* rs_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int rs_version(void);
+const char* rs_last_error_string(void);
+int rs_device_cu_count(void);
+
+/* ---- K1: fused multi-field gather ----------------------------------------------------------- */
+/* out[b,f,:] = table[row_offset[f] + idx[f,b], :]
+ * replaces Embedding_layer.forward: one nn.Embedding call per column + torch.stack
+ * (model/utils/Layers.py:137-167).  Out-of-range indices read the padding row and set *err_flag. */
+int rs_gather_fwd(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* table,
+                  float* out, int B, int F, int d, int* err_flag, rs_stream_t stream);
+
+/* One pass over the rows producing any of: emb_out [B,F,d]; sum_out [B,d] = sum_f e_f;
+ * bi_out [B,d] = 0.5*((sum_f e)^2 - sum_f e^2) (NFM Bi-Interaction, textbook form);
+ * lr_out [B] = sum_f table1[row] + bias[0]  (LinearRegression_layer.forward, Layers.py:107-109);
+ * fm_out [B] = 0.5*sum_k((sum_f e)^2 - sum_f e^2)  (model/FM/FM.py:27-30, model/DeepFM/DeepFM.py:47-49).
+ * Null outputs are skipped; table or table1 may be null when unused. */
+int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* table,
+                        const float* table1, const float* bias, float* emb_out, float* sum_out, float* bi_out,
+                        float* lr_out, float* fm_out, int B, int F, int d, int* err_flag, rs_stream_t stream);
+
+/* ---- K2e: MLP GEMMs on the matrix cores (fp32 in, fp32 accumulate) --------------------------- */
+/* C[M,N] = epi(op(A) op(B)),  epi(v) = act(v + bias[n]) * act'(mulsrc[m,n]) (each part optional).
+ * a_mc = 0: A is [M,K] row-major; 1: A is stored [K,M].  b_nc = 0: B is [N,K] (nn.Linear weight);
+ * 1: B is stored [K,N].  Replaces nn.Linear forward and its autograd backward inside MLPBlock /
+ * ResidualMLPBlock (model/utils/Layers.py:39-47, 84-94):
+ *   forward  H  = act(X W^T + b)          (a_mc=0, b_nc=0)
+ *   dX       dZ'= (dZ W) * act'(H_prev)   (a_mc=0, b_nc=1)
+ *   dW       dW = dZ^T X                  (a_mc=1, b_nc=1, split over the batch when splitk > 1)
+ * tile < 0 / splitk <= 0: chosen by rs_gemm_plan.  workspace is needed when the split count > 1. */
+size_t rs_gemm_workspace_bytes(int M, int N, int splitk);
+int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out /* host pointer */);
+int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
+                float* workspace, size_t workspace_bytes, rs_stream_t stream);
+
+/* out[n] = sum_m scale[m] * X[m,n] (scale optional): bias gradient of nn.Linear, dgamma/dbeta sums of
+ * LayerNorm, and (with scale) the weight gradient of a 1-wide layer. */
+size_t rs_colsum_workspace_bytes(int M, int N);
+int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, float* out, float* workspace,
+                  size_t workspace_bytes, rs_stream_t stream);
+
+/* 1-wide linear layer (the MLP head, model/DeepFM/DeepFM.py:35): h[m] = act(X[m,:].w + bias[0]) and
+ * dX[m,k] = dz[m] * w[k] * act'(X[m,k]). */
+int rs_rowdot_fwd(const float* X, int M, int K, const float* w, const float* bias, int act, float* h,
+                  rs_stream_t stream);
+int rs_rowdot_bwd_dx(const float* dz, const float* w, const float* X, int mul_act, int M, int K, float* dX,
+                     rs_stream_t stream);
+
+/* activation / normalisation layers of MLPBlock (Layers.py:14-29, 43-45) */
+int rs_act_fwd(const float* z, float* h, long long n, int act, const float* slope, rs_stream_t stream);
+int rs_act_bwd_num_partials(long long n);
+int rs_act_bwd(const float* dh, const float* z, const float* h, float* dz, long long n, int act, const float* slope,
+               float* dslope_partials, rs_stream_t stream);
+int rs_bn_fwd(const float* z, int M, int N, const float* gamma, const float* beta, float eps, int act, int training,
+              float momentum, float* mean, float* var, float* running_mean, float* running_var, float* xhat, float* h,
+              rs_stream_t stream);
+int rs_bn_bwd(const float* dh, const float* h, const float* xhat, int M, int N, int act, const float* gamma,
+              const float* var, float eps, float* dgamma, float* dbeta, float* dz, rs_stream_t stream);
+int rs_ln_fwd(const float* z, int M, int N, const float* gamma, const float* beta, float eps, int act, float* xhat,
+              float* rstd, float* h, rs_stream_t stream);
+int rs_ln_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gamma, int M, int N,
+              int act, float* dz, float* dy, float* dyxhat, rs_stream_t stream);
+int rs_add_f32(const float* a, const float* b, float* y, long long n, rs_stream_t stream);   /* residual add, Layers.py:94 */
+int rs_axpy_f32(float a, const float* x, float* y, long long n, rs_stream_t stream);         /* L2 term, BaseModel.py:214-231 */
+int rs_loss_add_reg(float* loss, const float* partials, const int* seg_end, const float* coef, int nseg,
+                    rs_stream_t stream);
+
+/* ---- loss head: sigmoid + F.binary_cross_entropy + dL/dlogit (BaseModel.py:145, LR.py:32) --- */
+int rs_bce_head(const float* z0, const float* z1, const float* z2, const float* labels_f32, const int64_t* labels_i64,
+                int B, float* logit_out, float* prob_out, float* loss_out, float* dz_out, float grad_scale,
+                float* sum_dz_out, const float* hlast, int act_last, float* dzh_out, float* sum_dzh_out,
+                rs_stream_t stream);
+
+/* ---- K2: interactions on gathered embeddings emb[B,F,d] -------------------------------------- */
+int rs_fm_fwd(const float* emb, int B, int F, int d, float* sum_out, float* bi_out, float* fm_out, rs_stream_t stream);
+int rs_fm_bwd(const float* emb, const float* S, const float* dfm, const float* dbi, int B, int F, int d, float* demb,
+              rs_stream_t stream);
+
+/* ---- K3: deterministic sparse embedding backward + optimizer (BaseModel.py:141-150) ---------- */
+/* plan: int32 scratch of rs_sort_plan_ints(F, cap) elements.  Per field, `nsrc` sub-lists of keys are
+ * concatenated (a columnar [F,B] batch is nsrc=1, sub_off[f]=f*B, sub_cnt[f]=B, pay_base[f]=f,
+ * pay_stride=F so that entry (f,b) names gradient row b*F+f), stably radix-sorted in LDS, and cut into
+ * segments (one per distinct non-padding row) and chunks (<= L entries, L = rs_sparse_window(d)). */
+size_t rs_sort_plan_ints(int F, int cap);
+int rs_sort_max_entries(void);
+int rs_sparse_window(int d);
+int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base, int pay_stride,
+                       int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
+                       const int64_t* row_offset, int* plan, rs_stream_t stream);
+/* Row gradient of every touched row = sum over its entries r (sample b = r / Fdiv) of
+ *   gout[r,:] + dfm[b]*(S[b,:] - emb[r,:])      and, for the 1-dim tables, g1src[r] + dlr[b]
+ * (each term optional).  Also writes rs_sparse_bwd_num_partials(F,cap,d) partial sums of ||g||^2. */
+int rs_sparse_bwd_num_partials(int F, int cap, int d);
+int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                         const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                         float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
+                         rs_stream_t stream);
+/* Optimizer step on the touched rows only (hyper: 8 floats, see rs_opt_prepare; scal[1] = clip coefficient). */
+int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                     float* table, float* m, float* v, float* table1, float* m1, float* v1, const float* hyper,
+                     const float* scal, rs_stream_t stream);
+/* Expand row gradients into dense [R,d] / [R] gradients (pre-zeroed by the caller): what nn.Embedding's
+ * autograd produces for torch's dense optimizers. */
+int rs_sparse_scatter_dense(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,
+                            float* grad, float* grad1, rs_stream_t stream);
+/* Dense flat-buffer optimizer step, sums of squares, and nn.utils.clip_grad_norm_ (BaseModel.py:148):
+ * scal[0] = sqrt(sum partials), scal[1] = min(1, max_norm/(scal[0]+1e-6)).
+ * hyper = {lr, beta1, beta2, eps, weight_decay, lr/(1-beta1^t), sqrt(1-beta2^t), reserved}. */
+int rs_dense_update(float* w, const float* g, float* m, float* v, long long n, int opt, const float* hyper,
+                    const float* scal, rs_stream_t stream);
+int rs_sumsq_partials(const float* x, long long n, float* partials, int nblocks, rs_stream_t stream);
+int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, rs_stream_t stream);
+int rs_opt_prepare(long long* step, float* hyper, rs_stream_t stream);
+int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
+                        rs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RS_HIP_H */

@@ -579,19 +579,24 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
         part_out[(long long)blockIdx.y * N + n] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
     }
 }
+// Stage 2: one workgroup per 64 columns; wave r adds partial rows r, r+4, ... (all loads of a lane are
+// independent), then the four waves' sums meet in LDS.
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int chunks, int N,
                                                             float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s[8];
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        for (int k = r; k < chunks; k += 16) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = 0.f;
-    for (int c = 0; c < chunks; c += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (c + u < chunks) s[u] += part[(long long)(c + u) * N + n];
+            for (int u = 0; u < 4; ++u)
+                if (k + 4 * u < chunks) s[u] += part[(long long)(k + 4 * u) * N + n];
+        }
     }
-    out[n] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[r][c] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (r == 0 && n < N) out[n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 }  // namespace
@@ -681,7 +686,7 @@ int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, floa
     dim3 grid(rs_cdiv(N, 256), chunks);
     if (vec) hipLaunchKernelGGL(colsum_stage1_kernel<true>, grid, dim3(256), 0, stream, X, M, N, ld, scale, workspace);
     else hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, stream, X, M, N, ld, scale, workspace);
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 256)), dim3(256), 0, stream, workspace, chunks, N, out);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 64)), dim3(256), 0, stream, workspace, chunks, N, out);
     RS_CHECK_LAUNCH("rs_colsum_f32");
     return RS_OK;
 }

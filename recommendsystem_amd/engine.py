@@ -36,9 +36,29 @@ _FUSABLE = (0, 1, 2, 3)
 N_DENSE_PARTIALS = 256
 
 
+class _Fork:
+    """Run the enclosed launches on a side stream, ordered after the work already queued on the
+    current stream, with their scratch taken from the side stream's own workspace."""
+
+    def __init__(self, side, ws):
+        self.side, self.ws = side, ws
+
+    def __enter__(self):
+        self.side.wait_stream(torch.cuda.current_stream())
+        self._sctx = torch.cuda.stream(self.side)
+        self._sctx.__enter__()
+        self._wctx = ops.use_workspace(self.ws)
+        self._wctx.__enter__()
+
+    def __exit__(self, *exc):
+        self._wctx.__exit__(*exc)
+        self._sctx.__exit__(*exc)
+        return False
+
+
 class FusedTrainer:
     def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
-                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None):
+                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = True):
         kind = getattr(model, "KIND", None)
         if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
@@ -102,6 +122,11 @@ class FusedTrainer:
         self._alloc_state()
         self._plans: Dict[int, ops.SparsePlan] = {}
         self.use_graph = use_graph
+        self.overlap = bool(overlap)
+        self.side_w = torch.cuda.Stream(device=dev)
+        self.side_sort = torch.cuda.Stream(device=dev)
+        self.ws_w = ops.Workspace(dev)
+        self.ws_sort = ops.Workspace(dev)
         self._graphs = {}
         self._graph_pool = None
         self.last = {}
@@ -236,9 +261,21 @@ class FusedTrainer:
                 out = ops.add(out, p)
         return out.view(-1, 1)
 
+    def _fork(self, side, ws):
+        """Context: run the enclosed launches on `side`, ordered after everything issued so far on the
+        current stream.  Returns immediately; join with current_stream().wait_stream(side)."""
+        return _Fork(side, ws)
+
     def _step_impl(self, idx: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         B = idx.shape[1]
         plan = self.plan(B)
+        main = torch.cuda.current_stream()
+        overlap = self.overlap
+        keep = []                    # intermediates read on side streams stay alive until the join
+        # The index sort needs only the batch: it runs beside the forward pass.
+        if overlap:
+            with self._fork(self.side_sort, self.ws_sort):
+                plan.sort_columnar(idx)
         parts, ctx = self.forward_parts(idx)
         head_fast = bool(self.blocks) and self._head_fast
         lastb = self.blocks[-1] if self.blocks else None
@@ -248,20 +285,31 @@ class FusedTrainer:
                             want_dzh=head_fast,
                             sum_dzh_out=self.gviews[id(lastb.fc.bias)] if head_fast else None)
         loss, dz = head["loss"], head["dz"]
+        keep += [parts, ctx, head]
 
         # ---- dense backward ------------------------------------------------------------------
+        # Critical chain on the main stream: dZ_l -> dX -> dZ_(l-1) ...; the weight/bias gradients of
+        # a layer depend only on its dZ and run beside the chain on the side stream.
         gout = None
         if self.blocks:
             cs = ctx["mlp"]
             dh = dz.view(B, 1)
             dz_ready = False
             top = len(self.blocks) - 1
+
+            def wgrad(fn):
+                if overlap:
+                    with self._fork(self.side_w, self.ws_w):
+                        fn()
+                else:
+                    fn()
+
             if head_fast:
                 _, xin, _ = cs[top]
                 dzh = head["dzh"]
                 prev = self.blocks[top - 1] if top > 0 else None
                 fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
-                ops.colsum(xin, out=self.gviews[id(lastb.fc.weight)].view(-1), scale=dzh)     # dW = dz^T X
+                wgrad(lambda: ops.colsum(xin, out=self.gviews[id(lastb.fc.weight)].view(-1), scale=dzh))   # dz^T X
                 dh = ops.rowdot_bwd_dx(dzh, lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0)
                 dz_ready = fuse_prev
                 top -= 1
@@ -269,25 +317,42 @@ class FusedTrainer:
                 b, c = self.blocks[i], cs[i]
                 prev = self.blocks[i - 1] if i > 0 else None
                 fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
-                r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
-                                     dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
-                                     mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0)
-                if b.normalization:
-                    self.gviews[id(b.norm_layer.weight)].copy_(r["dgamma"])
-                    self.gviews[id(b.norm_layer.bias)].copy_(r["dbeta"])
-                if r["dslope"] is not None:
-                    self.gviews[id(b.activation_func.weight)].copy_(r["dslope"])
-                dh, dz_ready = r["dx"], fuse_prev
+                if not b.normalization and b._act in _FUSABLE:
+                    dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
+                    keep.append(dzl)
+                    gW, gb = self.gviews[id(b.fc.weight)], self.gviews[id(b.fc.bias)]
+                    wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW),
+                                                              ops.colsum(dzl, out=gb)))
+                    dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
+                                  mul_act=prev._act if fuse_prev else 0)
+                else:
+                    r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
+                                         dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
+                                         mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0)
+                    if b.normalization:
+                        self.gviews[id(b.norm_layer.weight)].copy_(r["dgamma"])
+                        self.gviews[id(b.norm_layer.bias)].copy_(r["dbeta"])
+                    if r["dslope"] is not None:
+                        self.gviews[id(b.activation_func.weight)].copy_(r["dslope"])
+                    dh = r["dx"]
+                    keep.append(r)
+                dz_ready = fuse_prev
+                keep.append(dh)
             gout = dh.view(B * self.F, self.d)
 
-        # ---- embedding backward: sort, segment, reduce ----------------------------------------
+        if overlap:
+            main.wait_stream(self.side_sort)
+        else:
+            plan.sort_columnar(idx)
+        # ---- embedding backward: segment reduce of the sorted batch -----------------------------
         P = plan.partials
         n_sp = plan.n_partials
-        plan.sort_columnar(idx)
         plan.reduce(P[:n_sp], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
                     emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
                     dlr=dz if self.has_lr else None, Fdiv=self.F)
 
+        if overlap:
+            main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
         # ---- L2 terms, global norm, clip coefficient ------------------------------------------
         if self.net_reg:
             ops.axpy(self.net_reg, self.flat_w, self.flat_g)
@@ -326,6 +391,7 @@ class FusedTrainer:
                 ops.dense_update(t["w"].view(-1), t["g"].view(-1), t["m"].view(-1) if t["m"] is not None else None,
                                  t["v"].view(-1) if t["v"] is not None else None, self.opt, self.hyper, self.scal)
         self.last = {"dz": dz, "parts": parts}
+        del keep
         return loss
 
     def _add_reg_to_loss(self, loss):
