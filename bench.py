@@ -38,6 +38,7 @@ def parse():
     p.add_argument("--optimizer", type=str, default="Adam")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
     p.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
+    p.add_argument("--overlap", type=int, default=0, help="run weight-gradient GEMMs and the index sort on side streams")
     p.add_argument("--uniform", type=int, default=0, help="uniform instead of Zipf(1.1) indices")
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -110,13 +111,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    dist_ctx = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        from recommendsystem_amd.dist import ShardedTables
-        dist_ctx = ShardedTables  # constructed by the engine below
 
     from recommendsystem_amd import data, ops
     from recommendsystem_amd.prof import KernelTimer
@@ -127,7 +125,7 @@ def main():
         from recommendsystem_amd.dist import DistributedTrainer
         eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.graph))
     else:
-        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph))
+        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
 
     nb = max(1, args.distinct_batches)
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
@@ -163,14 +161,17 @@ def main():
     if timer is None:
         # graph replay cannot carry events: time the same launches in an eager pass of the same K steps
         eager = eng
+        was_graph = eager.use_graph
         eager.use_graph = False
         with KernelTimer() as timer:
             for i in range(args.steps):
                 eager.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
-        eager.use_graph = True
+        eager.use_graph = was_graph
         measured_in = "separate eager pass of the same K steps (graph replay cannot carry events)"
     summ = timer.summary()
     final_loss = float(loss.item())
+    if world > 1:
+        eng.check()          # bucket overflow / index range flags of the exchange (device sync, outside the timing)
 
     if world > 1:
         import torch.distributed as dist
@@ -238,7 +239,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
                        "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
                        "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
-                       "total_table_rows": sum(vocab), "hip_graph": bool(args.graph),
+                       "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": "single GPU" if world == 1 else f"dp{world} + row-sharded tables (RCCL all-to-all)"},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
             "kernel_us_per_step": {k: round(v, 1) for k, v in per_step.items()},

@@ -150,6 +150,20 @@ int rs_opt_prepare(long long* step, float* hyper, rs_stream_t stream);
 int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
                         rs_stream_t stream);
 
+/* ---- row-sharded tables: device side of the all-to-all exchange (no reference counterpart: the
+ * reference is single-device; semantics are those of Embedding_layer.forward / its backward on the
+ * union of all ranks' batches).  Row i of a field lives on rank i % N at local index i / N + 1. ---- */
+int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, int cap_b, long long* send_idx,
+                   int* route, int* overflow_flag, rs_stream_t stream);
+int rs_shard_gather(const long long* recv_idx, const int64_t* local_row_offset, const int64_t* local_vocab, int N,
+                    int F, int cap_b, int d, const float* table, const float* table1, float* rows, float* rows1,
+                    int* err_flag, rs_stream_t stream);
+int rs_shard_expand(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rows,
+                    const float* rows1, float* emb, float* lr1, rs_stream_t stream);
+int rs_shard_pack(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rowgrad,
+                  const float* rowgrad1, float* grads, float* grads1, rs_stream_t stream);
+int rs_shard_counts(const long long* recv_idx, int N, int F, int cap_b, int* sub_cnt, rs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,28 +18,11 @@
 //      scatter_rowgrad      alternative consumer: expand into a dense (R, d) gradient for callers
 //                           that keep the reference's dense torch optimizers.
 #include "common.h"
+#include "plan.h"
 
 namespace {
 
 constexpr int SORT_THREADS = 1024;
-
-// int32 scratch layout shared by every kernel of this file ("plan"), capacity `cap` entries per field:
-//   sorted_src [F,cap] | entry_chunk [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
-//   seg_first_chunk [F,cap+1] | counts [F,4]
-struct PlanView {
-    int* sorted_src; int* entry_chunk; int* chunk_start; int* seg_row; int* seg_first_chunk; int* counts;
-};
-inline PlanView carve_plan(int* plan, int F, int cap) {
-    PlanView v;
-    int* p = plan;
-    v.sorted_src = p; p += (size_t)F * cap;
-    v.entry_chunk = p; p += (size_t)F * cap;
-    v.chunk_start = p; p += (size_t)F * (cap + 1);
-    v.seg_row = p; p += (size_t)F * cap;
-    v.seg_first_chunk = p; p += (size_t)F * (cap + 1);
-    v.counts = p;
-    return v;
-}
 
 struct SortArgs {
     const int64_t* keys;      // index storage (int64, as the reference's .long() batches)
@@ -52,6 +35,7 @@ struct SortArgs {
     const int64_t* row_offset;// [F]
     int* sorted_src;          // [F, cap]   gradient-row index of the i-th entry in key order
     int* entry_chunk;         // [F, cap]   chunk of the i-th entry in key order (-1: padding entry)
+    int* entry_seg;           // [F, cap]   segment (distinct row) of the i-th entry (-1: padding entry)
     int* chunk_start;         // [F, cap+1] first sorted position of each chunk (+ sentinel)
     int* seg_row;             // [F, cap]   stacked-table row of each segment
     int* seg_first_chunk;     // [F, cap+1] first chunk of each segment (+ sentinel)
@@ -161,6 +145,7 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
     int seg = (ex & 0xFFFF), chk = (ex >> 16);
     int* sorted_src = a.sorted_src + (long long)f * a.cap;
     int* entry_chunk = a.entry_chunk + (long long)f * a.cap;
+    int* entry_seg = a.entry_seg + (long long)f * a.cap;
     int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
     int* seg_row = a.seg_row + (long long)f * a.cap;
     int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
@@ -176,7 +161,9 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
                 ++seg;
             }
             if (flags[j] & 2) { chunk_start[chk] = i; ++chk; }
-            entry_chunk[i] = ((unsigned)(it[j] >> 32) == 0u) ? -1 : chk - 1;
+            const bool pad = ((unsigned)(it[j] >> 32) == 0u);
+            entry_chunk[i] = pad ? -1 : chk - 1;
+            entry_seg[i] = pad ? -1 : seg - 1;
         }
     }
     if (t == 0) {
@@ -504,9 +491,9 @@ int window_for(int d) {
 extern "C" {
 
 // Bytes of int32 scratch per field-sort output set with capacity `cap` entries per field:
-//   sorted_src [F,cap] | entry_chunk [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
+//   sorted_src [F,cap] | entry_chunk [F,cap] | entry_seg [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
 //   seg_first_chunk [F,cap+1] | counts [F,4]
-size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (5 * (size_t)cap + 2 + 4); }
+size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (6 * (size_t)cap + 2 + 4); }
 
 int rs_sort_max_entries(void) { return SORT_THREADS * 16; }
 
@@ -525,8 +512,9 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
     a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
     const PlanView pv = carve_plan(plan, F, cap);
-    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.chunk_start = pv.chunk_start;
-    a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk; a.counts = pv.counts;
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.entry_seg = pv.entry_seg;
+    a.chunk_start = pv.chunk_start; a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk;
+    a.counts = pv.counts;
     int items = 1;
     while (items * SORT_THREADS < max_entries) items <<= 1;
     if (items < 4) items = 4;

@@ -1,0 +1,357 @@
+"""Multi-GPU training of the hot path on one 8xMI355X node: one process per GPU.
+
+* batch: data-parallel, every rank steps on its own B samples (weak scaling);
+* dense towers: replicated; ONE all-reduce of the flat gradient buffer per step (RCCL over xGMI);
+* embedding tables: row-sharded, row i of every field on rank ``i % N`` at local index ``i // N + 1``
+  (local row 0 is a zero dummy so "index 0 = padding" holds on every rank; ``% N`` also spreads the
+  frequency-sorted hot low rows evenly).  Per step: all-to-all of DISTINCT indices, all-to-all of their
+  rows back, and on backward all-to-all of one gradient per distinct index; the owner merges the N
+  contributions per row with the same sort + segmented-reduce kernels as the single-GPU path and
+  updates its shard.  Buckets have a fixed capacity, so every collective is rectangular and no count
+  visits the host;
+* gradient clipping: one scalar all-reduce of the sharded ||g||^2.
+
+The reference has no collective of any kind; semantics are those of its single-device step
+(model/utils/BaseModel.py:141-150) on the union of all ranks' batches, with mean loss over N*B samples.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import RSError, call, ptr, stream
+from .engine import FusedTrainer, N_DENSE_PARTIALS
+from .ops import FieldLayout, SparsePlan
+
+
+# -------------------------------------------------------------------------------------------------
+# sharding arithmetic (host)
+# -------------------------------------------------------------------------------------------------
+class ShardSpec:
+    def __init__(self, vocab_sizes: List[int], world: int, rank: int):
+        self.vocab = [int(v) for v in vocab_sizes]
+        self.N, self.rank = int(world), int(rank)
+        # rows i < V with i % N == rank, plus the dummy row 0
+        self.local_vocab = [self.owned_count(v, self.rank) + 1 for v in self.vocab]
+
+    def owned_count(self, v: int, r: int) -> int:
+        return (v - r + self.N - 1) // self.N if v > r else 0
+
+    @staticmethod
+    def owner(i, N):
+        return i % N
+
+    @staticmethod
+    def local_index(i, N):
+        return i // N + 1
+
+    def bucket_capacity(self, B: int, slack: float = 1.5, extra: int = 64) -> int:
+        """Entries per (owner, field) bucket: distinct keys of one field spread ~uniformly over owners."""
+        cap = int(-(-B // self.N) * slack) + extra
+        return min(cap, B)
+
+    def shard_table(self, full: torch.Tensor) -> torch.Tensor:
+        """[sum V_f, d] stacked global table -> this rank's stacked local table [sum local_vocab, d]."""
+        out, o = [], 0
+        for v in self.vocab:
+            rows = full[o + self.rank:o + v:self.N]
+            out.append(torch.zeros((1,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device))
+            out.append(rows)
+            o += v
+        return torch.cat(out, 0).contiguous()
+
+    def unshard_into(self, full: torch.Tensor, shards: List[torch.Tensor]):
+        """Inverse of shard_table given every rank's local table (rank order)."""
+        for r, sh in enumerate(shards):
+            o = lo = 0
+            for v in self.vocab:
+                n = self.owned_count(v, r)
+                full[o + r:o + v:self.N] = sh[lo + 1:lo + 1 + n]
+                o += v
+                lo += n + 1
+
+
+# -------------------------------------------------------------------------------------------------
+# collectives
+# -------------------------------------------------------------------------------------------------
+class Comm:
+    """torch.distributed wrapper.  stage_cpu=True moves tensors through host memory around each
+    collective (for the gloo backend, which is what the CPU tests and single-GPU rehearsals use)."""
+
+    def __init__(self, group=None, stage_cpu: bool = False):
+        self.group = group
+        self.stage_cpu = stage_cpu
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        """Equal split: chunk s of `inp` goes to rank s; chunk s of `out` comes from rank s."""
+        if self.stage_cpu and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o.view(-1), inp.cpu().view(-1), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
+
+    def all_reduce(self, t: torch.Tensor):
+        if self.stage_cpu and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0):
+        if self.stage_cpu and t.is_cuda:
+            c = t.cpu()
+            dist.broadcast(c, src, group=self.group)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src, group=self.group)
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        src = t.cpu() if (self.stage_cpu and t.is_cuda) else t
+        outs = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(outs, src.contiguous(), group=self.group)
+        return [o.to(t.device) for o in outs]
+
+
+# -------------------------------------------------------------------------------------------------
+# device kernels of the exchange (HIP)
+# -------------------------------------------------------------------------------------------------
+class HipShardKernels:
+    """The device side of the exchange on librs_hip.so.  tests/test_dist_cpu.py substitutes a torch-CPU
+    stand-in with the same methods to rehearse the protocol under gloo."""
+
+    def __init__(self, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool, cap_b: int, device):
+        self.spec, self.B, self.d, self.cap_b = spec, B, d, cap_b
+        self.with_emb, self.with_lr = with_emb, with_lr
+        self.F = len(spec.vocab)
+        self.layout_req = FieldLayout(spec.vocab, device)            # requester: global indices
+        self.layout_own = FieldLayout(spec.local_vocab, device)      # owner: local indices (+1 shift)
+        self.plan_req = SparsePlan(self.layout_req, cap=B, d=d, with_lr=with_lr)
+        self.plan_own = SparsePlan(self.layout_own, cap=spec.N * cap_b, d=d, with_lr=with_lr)
+        N, F = spec.N, self.F
+        sf = torch.arange(N * F, dtype=torch.int32, device=device)
+        self.sub_off = sf * (cap_b + 1) + 1
+        self.pay_base = sf * cap_b
+        self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
+        self.scratch_partials = torch.zeros(self.plan_req.n_partials, dtype=torch.float32, device=device)
+
+    def sort_batch(self, idx):
+        self.plan_req.sort_columnar(idx)
+
+    def route(self, send_idx, route, overflow):
+        call("rs_shard_route", ptr(self.plan_req.plan), self.F, self.B, ptr(self.layout_req.row_offset_t), self.spec.N,
+             self.cap_b, ptr(send_idx), ptr(route), ptr(overflow), stream())
+
+    def gather(self, recv_idx, table, table1, rows, rows1):
+        call("rs_shard_gather", ptr(recv_idx), ptr(self.layout_own.row_offset_t), ptr(self.layout_own.vocab_t),
+             self.spec.N, self.F, self.cap_b, self.d, ptr(table), ptr(table1), ptr(rows), ptr(rows1),
+             ptr(self.layout_own.err_flag), stream())
+
+    def expand(self, route, rows, rows1, emb, lr1):
+        call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d, ptr(rows),
+             ptr(rows1), ptr(emb), ptr(lr1), stream())
+
+    def reduce_local(self, gout, dfm, S, emb, dlr):
+        """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1)."""
+        self.plan_req.reduce(self.scratch_partials, gout=gout, dfm=dfm, S=S, emb=emb, dlr=dlr, Fdiv=self.F)
+
+    def pack(self, route, grads, grads1):
+        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d,
+             ptr(self.plan_req.rowgrad) if grads is not None else None,
+             ptr(self.plan_req.rowgrad1) if grads1 is not None else None, ptr(grads), ptr(grads1), stream())
+
+    def merge(self, recv_idx, grads, grads1, partials):
+        """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows."""
+        N = self.spec.N
+        call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
+        self.plan_own.sort_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
+                                 max_entries=N * self.cap_b)
+        self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
+                             g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
+
+    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1):
+        self.plan_own.update(opt, hyper, scal, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
+
+    @property
+    def n_own_partials(self):
+        return self.plan_own.n_partials
+
+
+# -------------------------------------------------------------------------------------------------
+# the exchange protocol
+# -------------------------------------------------------------------------------------------------
+class ShardedExchange:
+    def __init__(self, kernels, comm: Comm, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool,
+                 cap_b: int, device):
+        self.k, self.comm, self.spec = kernels, comm, spec
+        N, F = spec.N, len(spec.vocab)
+        self.N, self.F, self.B, self.d, self.cap_b = N, F, B, d, cap_b
+        self.with_emb, self.with_lr = with_emb, with_lr
+        dev = device
+        z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
+        self.send_idx = z((N, F, cap_b + 1), torch.int64)
+        self.recv_idx = z((N, F, cap_b + 1), torch.int64)
+        self.route = torch.full((F, B), -1, dtype=torch.int32, device=dev)
+        self.overflow = z((1,), torch.int32)
+        self.rows_s = z((N, F, cap_b, d)) if with_emb else None
+        self.rows_r = z((N, F, cap_b, d)) if with_emb else None
+        self.rows1_s = z((N, F, cap_b)) if with_lr else None
+        self.rows1_r = z((N, F, cap_b)) if with_lr else None
+        # gradient buffers reuse the row buffers' shapes
+        self.g_s = z((N, F, cap_b, d)) if with_emb else None
+        self.g_r = z((N, F, cap_b, d)) if with_emb else None
+        self.g1_s = z((N, F, cap_b)) if with_lr else None
+        self.g1_r = z((N, F, cap_b)) if with_lr else None
+
+    def forward(self, idx, table, table1, emb_out, lr1_out):
+        """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values."""
+        k, c = self.k, self.comm
+        k.sort_batch(idx)
+        k.route(self.send_idx, self.route, self.overflow)
+        c.all_to_all(self.recv_idx, self.send_idx)
+        k.gather(self.recv_idx, table, table1, self.rows_s, self.rows1_s)
+        if self.with_emb:
+            c.all_to_all(self.rows_r, self.rows_s)
+        if self.with_lr:
+            c.all_to_all(self.rows1_r, self.rows1_s)
+        k.expand(self.route, self.rows_r, self.rows1_r, emb_out, lr1_out)
+
+    def backward(self, gout, dfm, S, emb, dlr, own_partials):
+        """Per-entry gradient terms of the local batch -> summed row gradients on the owners."""
+        k, c = self.k, self.comm
+        k.reduce_local(gout, dfm, S, emb, dlr)
+        k.pack(self.route, self.g_s, self.g1_s)
+        if self.with_emb:
+            c.all_to_all(self.g_r, self.g_s)
+        if self.with_lr:
+            c.all_to_all(self.g1_r, self.g1_s)
+        k.merge(self.recv_idx, self.g_r, self.g1_r, own_partials)
+
+    def check_overflow(self):
+        """Host check (device sync): a bucket overflow drops rows; raise so the caller can re-plan."""
+        if int(self.overflow.item()) != 0:
+            self.overflow.zero_()
+            raise RSError("row-shard exchange: a (rank, field) bucket overflowed its capacity; "
+                          "raise bucket_slack")
+
+
+# -------------------------------------------------------------------------------------------------
+# the distributed fused step
+# -------------------------------------------------------------------------------------------------
+class DistributedTrainer(FusedTrainer):
+    """FusedTrainer with row-sharded tables and a data-parallel dense tower (see the module docstring).
+
+    Every rank must build the same model from the same seed before constructing the trainer; the
+    trainer keeps only this rank's shard of each table as training state.  ``sync_to_model()``
+    all-gathers the shards back into the model's parameters (for evaluation / checkpoints).
+    """
+
+    def __init__(self, model, mode: str = "sparse", use_graph: bool = False, group=None, stage_cpu: bool = False,
+                 bucket_slack: float = 1.5, **kw):
+        if mode != "sparse":
+            raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
+        if use_graph:
+            use_graph = False            # collectives run between kernel segments; the step is issued eagerly
+        self.comm = Comm(group, stage_cpu=stage_cpu)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        self.bucket_slack = bucket_slack
+        super().__init__(model, mode="sparse", use_graph=False, **kw)
+        self._sort_can_fork = False
+        vocab = self.layout.vocab_sizes
+        self.spec = ShardSpec(vocab, self.world, self.rank)
+        # this rank's shards (training state) and their optimizer moments
+        adam = self.opt in ("Adam", "AdamW")
+        need_m = adam or self.opt == "Adagrad"
+        zl = torch.zeros_like
+        self.shard = self.spec.shard_table(self.tab.stacked) if self.has_emb else None
+        self.shard1 = self.spec.shard_table(self.tab1.stacked).view(-1) if self.has_lr else None
+        self.shard_m = zl(self.shard) if (self.has_emb and need_m) else None
+        self.shard_v = zl(self.shard) if (self.has_emb and adam) else None
+        self.shard1_m = zl(self.shard1) if (self.has_lr and need_m) else None
+        self.shard1_v = zl(self.shard1) if (self.has_lr and adam) else None
+        for t in self.tables:            # the replicated full tables carry no optimizer state here
+            t["m"] = t["v"] = None
+        self._ex = {}
+        self.ones_F = torch.ones(self.F, dtype=torch.float32, device=self.device)
+        # the dense tower must start identical on every rank
+        self.comm.broadcast(self.flat_w, 0)
+
+    def exchange(self, B: int) -> ShardedExchange:
+        if B not in self._ex:
+            cap_b = self.spec.bucket_capacity(B, slack=self.bucket_slack)
+            k = HipShardKernels(self.spec, B, self.d, self.has_emb, self.has_lr, cap_b, self.device)
+            ex = ShardedExchange(k, self.comm, self.spec, B, self.d, self.has_emb, self.has_lr, cap_b, self.device)
+            ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
+            ex.sq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._ex[B] = ex
+        return self._ex[B]
+
+    # ---- hooks -----------------------------------------------------------------------------------
+    def _grad_scale(self) -> float:
+        return 1.0 / self.world          # mean over the N*B samples of the global batch
+
+    def _embed_forward(self, idx):
+        B = idx.shape[1]
+        ex = self.exchange(B)
+        dev = self.device
+        emb = torch.empty((B, self.F, self.d), dtype=torch.float32, device=dev) if self.has_emb else None
+        lr1 = torch.empty((B, self.F), dtype=torch.float32, device=dev) if self.has_lr else None
+        ex.forward(idx, self.shard, self.shard1, emb.view(B * self.F, self.d) if emb is not None else None,
+                   lr1.view(-1) if lr1 is not None else None)
+        r = {"emb": emb}
+        if self.has_fm:
+            r.update(ops.fm_fwd(emb, want_sum=True, want_fm=True))
+        if self.has_lr:
+            r["lr"] = ops.rowdot_fwd(lr1, self.ones_F, self.lrm.bias.data, 0)     # sum_f w_f[idx] + bias
+        return r
+
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already):
+        B = idx.shape[1]
+        ex = self.exchange(B)
+        ex.backward(gout, dz if self.has_fm else None, ctx["S"],
+                    ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
+                    ex.own_partials)
+        # ||g||^2 of the owned rows, summed over ranks (every rank owns disjoint rows)
+        ops.colsum(ex.own_partials.view(-1, 1), out=ex.sq)
+        self.comm.all_reduce(ex.sq)
+        P = plan.partials
+        P[:plan.n_partials].zero_()
+        P[0:1].copy_(ex.sq)
+
+    def _reduce_dense_grads(self):
+        self.comm.all_reduce(self.flat_g)
+
+    def _embed_update(self, plan):
+        # `plan` is the base class's per-batch-size plan (its partial buffer carries the norm); the update
+        # runs on the owner-side plan of the exchange
+        ex = self._ex[plan.cap]
+        ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
+                    self.shard1_m, self.shard1_v)
+
+    # ---- utilities ---------------------------------------------------------------------------------
+    def sync_to_model(self):
+        """All-gather the shards into the model's (replicated) embedding parameters."""
+        if self.has_emb:
+            self.spec.unshard_into(self.tab.stacked, self._gather_shards(self.shard))
+        if self.has_lr:
+            self.spec.unshard_into(self.tab1.stacked, [s.view(-1, 1) for s in self._gather_shards(self.shard1.view(-1, 1))])
+
+    def _gather_shards(self, shard):
+        # shards differ in length by at most F rows across ranks: pad to the longest
+        n = torch.tensor([shard.shape[0]], dtype=torch.int64, device=shard.device)
+        ns = [int(x.item()) for x in self.comm.all_gather(n)]
+        mx = max(ns)
+        pad = torch.zeros((mx,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        pad[:shard.shape[0]] = shard
+        return [g[:k] for g, k in zip(self.comm.all_gather(pad), ns)]
+
+    def check(self):
+        for ex in self._ex.values():
+            ex.check_overflow()
+            ex.k.layout_own.check_indices()

@@ -58,7 +58,7 @@ class _Fork:
 
 class FusedTrainer:
     def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
-                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = True):
+                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = False):
         kind = getattr(model, "KIND", None)
         if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
@@ -123,6 +123,7 @@ class FusedTrainer:
         self._plans: Dict[int, ops.SparsePlan] = {}
         self.use_graph = use_graph
         self.overlap = bool(overlap)
+        self._sort_can_fork = True
         self.side_w = torch.cuda.Stream(device=dev)
         self.side_sort = torch.cuda.Stream(device=dev)
         self.ws_w = ops.Workspace(dev)
@@ -210,11 +211,7 @@ class FusedTrainer:
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
-        table = self.tab.stacked if self.has_emb else None
-        table1 = self.tab1.stacked if self.has_lr else None
-        bias = self.lrm.bias.data if self.has_lr else None
-        r = ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
-                                 want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
+        r = self._embed_forward(idx)
         ctx["emb"] = r.get("emb")
         ctx["S"] = r.get("sum")
         if self.has_lr:
@@ -246,6 +243,37 @@ class FusedTrainer:
             parts.append(h.view(B))
         return parts, ctx
 
+    # ---- embedding hooks (overridden by the row-sharded multi-GPU trainer) -----------------------
+    def _embed_forward(self, idx):
+        """dict(emb [B,F,d], sum [B,d], lr [B], fm [B]) as needed by the model kind: K1, one launch."""
+        table = self.tab.stacked if self.has_emb else None
+        table1 = self.tab1.stacked if self.has_lr else None
+        bias = self.lrm.bias.data if self.has_lr else None
+        return ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
+                                    want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
+
+    def _grad_scale(self) -> float:
+        return 1.0
+
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already):
+        """Row gradients of the touched rows; fills plan.partials[:plan.n_partials] with ||g||^2 partials."""
+        B = idx.shape[1]
+        if not sorted_already:
+            plan.sort_columnar(idx)
+        plan.reduce(plan.partials[:plan.n_partials], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
+                    emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
+                    dlr=dz if self.has_lr else None, Fdiv=self.F)
+
+    def _reduce_dense_grads(self):
+        """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
+
+    def _embed_update(self, plan):
+        te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+        plan.update(self.opt, self.hyper, self.scal,
+                    table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
+                    table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
+                    v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+
     def _bump_bn_counters(self):
         for b in self.blocks:
             if b.normalization == "bn" and self.model.training:
@@ -273,13 +301,14 @@ class FusedTrainer:
         overlap = self.overlap
         keep = []                    # intermediates read on side streams stay alive until the join
         # The index sort needs only the batch: it runs beside the forward pass.
-        if overlap:
+        fork_sort = overlap and self._sort_can_fork
+        if fork_sort:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
         parts, ctx = self.forward_parts(idx)
         head_fast = bool(self.blocks) and self._head_fast
         lastb = self.blocks[-1] if self.blocks else None
-        head = ops.bce_head(parts, labels, want_dz=True,
+        head = ops.bce_head(parts, labels, want_dz=True, grad_scale=self._grad_scale(),
                             sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None,
                             hlast=parts[-1] if head_fast else None, act_last=lastb._act if head_fast else 0,
                             want_dzh=head_fast,
@@ -340,24 +369,19 @@ class FusedTrainer:
                 keep.append(dh)
             gout = dh.view(B * self.F, self.d)
 
-        if overlap:
+        if fork_sort:
             main.wait_stream(self.side_sort)
-        else:
-            plan.sort_columnar(idx)
         # ---- embedding backward: segment reduce of the sorted batch -----------------------------
         P = plan.partials
         n_sp = plan.n_partials
-        plan.reduce(P[:n_sp], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
-                    emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
-                    dlr=dz if self.has_lr else None, Fdiv=self.F)
+        self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort)
 
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
         # ---- L2 terms, global norm, clip coefficient ------------------------------------------
         if self.net_reg:
             ops.axpy(self.net_reg, self.flat_w, self.flat_g)
-        if self.dist is not None:
-            self.dist.allreduce_dense(self.flat_g)
+        self._reduce_dense_grads()
         dense_p = P[n_sp:n_sp + N_DENSE_PARTIALS]
         ops.sumsq_partials(self.flat_g, dense_p)
         if self.mode == "sparse":
@@ -381,11 +405,7 @@ class FusedTrainer:
         # ---- optimizer --------------------------------------------------------------------------
         ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
         if self.mode == "sparse":
-            te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
-            plan.update(self.opt, self.hyper, self.scal,
-                        table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
-                        table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
-                        v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+            self._embed_update(plan)
         else:
             for t in self.tables:
                 ops.dense_update(t["w"].view(-1), t["g"].view(-1), t["m"].view(-1) if t["m"] is not None else None,

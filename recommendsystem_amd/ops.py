@@ -305,11 +305,11 @@ class SparsePlan:
 
     # views into the plan (for tests / inspection)
     def counts(self):
-        off = self.F * (5 * self.cap + 2)
+        off = self.F * (6 * self.cap + 2)
         return self.plan[off:off + 4 * self.F].view(self.F, 4)
 
     def seg_rows(self):
-        off = 2 * self.F * self.cap + self.F * (self.cap + 1)
+        off = 3 * self.F * self.cap + self.F * (self.cap + 1)
         return self.plan[off:off + self.F * self.cap].view(self.F, self.cap)
 
     def columnar_lists(self, B: int):

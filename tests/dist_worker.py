@@ -1,0 +1,174 @@
+"""One rank of the multi-process tests (started by test_dist_cpu.py / test_dist_gpu.py).
+
+    python dist_worker.py cpu <outdir>     host-side exchange protocol under gloo with torch-CPU stand-in kernels
+    python dist_worker.py gpu <outdir> <kind> <optimizer>
+                                           DistributedTrainer on cuda:0 (all ranks share the one GPU of the
+                                           test box), gloo with host staging in place of RCCL
+
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+VOCAB = [7, 50, 3, 400, 1000, 23]
+B, D = 96, 8
+
+
+def rank_batch(rank, vocab=VOCAB, batch=B, zero_every=11):
+    g = torch.Generator().manual_seed(100 + rank)
+    idx = torch.stack([torch.randint(1, v, (batch,), generator=g) for v in vocab], 0)
+    idx[:, ::zero_every] = 0                              # padding entries
+    idx[1, :] = idx[1, 0].item() if idx[1, 0] > 0 else 5  # one field with a single hot key
+    labels = (torch.rand(batch, generator=g) < 0.3).long()
+    return idx, labels
+
+
+def full_tables(vocab=VOCAB, d=D):
+    g = torch.Generator().manual_seed(7)
+    R = sum(vocab)
+    t = torch.randn(R, d, generator=g)
+    t1 = torch.randn(R, generator=g)
+    o = 0
+    for v in vocab:
+        t[o] = 0
+        t1[o] = 0
+        o += v
+    return t, t1
+
+
+def offsets(vocab):
+    off, o = [], 0
+    for v in vocab:
+        off.append(o)
+        o += v
+    return torch.tensor(off).view(-1, 1)
+
+
+def run_cpu(outdir):
+    from recommendsystem_amd.dist import Comm, ShardSpec, ShardedExchange
+    from shard_cpu_kernels import TorchShardKernels
+    rank, N = dist.get_rank(), dist.get_world_size()
+    comm = Comm()
+    spec = ShardSpec(VOCAB, N, rank)
+    F = len(VOCAB)
+    T, T1 = full_tables()
+    shard, shard1 = spec.shard_table(T), spec.shard_table(T1.view(-1, 1)).view(-1)
+    assert shard.shape[0] == sum(spec.local_vocab)
+
+    # shard <-> full round trip through all_gather
+    mx = torch.tensor([shard.shape[0]])
+    sizes = [int(x) for x in comm.all_gather(mx)]
+    pad = torch.zeros(max(sizes), D)
+    pad[:shard.shape[0]] = shard
+    back = torch.zeros_like(T)
+    spec.unshard_into(back, [g[:k] for g, k in zip(comm.all_gather(pad), sizes)])
+    assert torch.equal(back, T)
+
+    idx, _ = rank_batch(rank)
+    cap_b = spec.bucket_capacity(B)
+    k = TorchShardKernels(spec, B, D, True, True, cap_b)
+    ex = ShardedExchange(k, comm, spec, B, D, True, True, cap_b, "cpu")
+    emb, lr1 = torch.full((B * F, D), 9.0), torch.full((B * F,), 9.0)
+    ex.forward(idx, shard, shard1, emb, lr1)
+    flat = (idx + offsets(VOCAB)).t().reshape(-1)                  # entry b*F+f
+    assert torch.equal(emb, T[flat]), "gathered rows differ"
+    assert torch.equal(lr1, T1[flat])
+    ex.check_overflow()
+
+    # backward: the owners' merged gradients equal the global dense gradient restricted to their rows
+    g = torch.Generator().manual_seed(500 + rank)
+    gout = torch.randn(B * F, D, generator=g)
+    dlr = torch.randn(B, generator=g)
+    part = torch.zeros(k.n_own_partials)
+    ex.backward(gout, None, None, None, dlr, part)
+    all_idx = comm.all_gather(idx)
+    all_g = comm.all_gather(gout)
+    all_d = comm.all_gather(dlr)
+    G, G1 = torch.zeros_like(T), torch.zeros_like(T1)
+    for r in range(N):
+        fl = (all_idx[r] + offsets(VOCAB)).t().reshape(-1)
+        keep = (all_idx[r].t().reshape(-1) > 0)
+        G.index_add_(0, fl[keep], all_g[r][keep])
+        G1.index_add_(0, fl[keep], all_d[r].repeat_interleave(F)[keep])
+    torch.testing.assert_close(k.own_grad, spec.shard_table(G), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(k.own_grad1, spec.shard_table(G1.view(-1, 1)).view(-1), rtol=1e-5, atol=1e-6)
+    sq = part[:1].clone()
+    comm.all_reduce(sq)
+    torch.testing.assert_close(sq[0], (G ** 2).sum() + (G1 ** 2).sum(), rtol=1e-5, atol=0)
+
+    # a bucket that is too small is reported, and the collectives still line up
+    k2 = TorchShardKernels(spec, B, D, True, False, 4)
+    ex2 = ShardedExchange(k2, comm, spec, B, D, True, False, 4, "cpu")
+    ex2.forward(idx, shard, None, emb, None)
+    flag = ex2.overflow.clone()
+    comm.all_reduce(flag)
+    assert int(flag) > 0
+    if int(ex2.overflow) != 0:
+        try:
+            ex2.check_overflow()
+        except RuntimeError as e:
+            assert "overflow" in str(e)
+        else:
+            raise AssertionError("overflow not reported")
+    open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+
+
+def run_gpu(outdir, kind, optimizer):
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd.base_model import random_all
+    from recommendsystem_amd.dist import DistributedTrainer
+    rank, N = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    vocab = [7, 50, 3, 400, 1000, 23, 5000, 64]
+    batch, d, steps = 256, 8, 3
+    random_all(11)
+    rec = data.criteo_x1_recorder(embedding_dim=d, batch_size=batch, vocab_sizes=vocab)
+    kw = dict(optimizer_type=optimizer if optimizer != "Adagrad" else "SGD")
+    if kind == "deepfm":
+        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+    elif kind == "fm":
+        m = models.FM(rec, 1e-2, 0, **kw)
+    elif kind == "lr":
+        m = models.LR(rec, 1e-2, 0, **kw)
+    else:
+        m = models.DNN(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+    # larger initial rows than the reference's 1e-4 so that every term of the gradient matters
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 2 and p.shape[0] in vocab:
+                p[1:].normal_(0, 0.05)
+    m.train()
+    eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
+    losses = []
+    for s in range(steps):
+        idx, y = rank_batch(rank + 10 * s, vocab, batch, zero_every=17)
+        loss = eng.step_tensors(idx.cuda(), y.cuda())
+        losses.append(float(loss.item()))
+    eng.check()
+    eng.sync_to_model()
+    if rank == 0:
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        np.savez(os.path.join(outdir, "state.npz"), **sd)
+    np.save(os.path.join(outdir, f"loss{rank}.npy"), np.array(losses))
+    open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+
+
+if __name__ == "__main__":
+    mode, outdir = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    try:
+        if mode == "cpu":
+            run_cpu(outdir)
+        else:
+            run_gpu(outdir, sys.argv[3], sys.argv[4])
+    finally:
+        dist.destroy_process_group()

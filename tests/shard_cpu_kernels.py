@@ -1,0 +1,129 @@
+"""Torch-CPU stand-in for recommendsystem_amd.dist.HipShardKernels (test infrastructure only).
+
+Same methods and the same buffer layouts (buckets [N, F, cap_b+1] with the count in slot 0, route codes
+o*cap_b + r, rows [N, F, cap_b, d]), written as plain loops, so that the host-side exchange protocol
+(ShardedExchange + Comm + ShardSpec) can be rehearsed with the gloo backend on a machine without a GPU.
+"""
+import torch
+
+
+class TorchShardKernels:
+    def __init__(self, spec, B, d, with_emb, with_lr, cap_b):
+        self.spec, self.B, self.d, self.cap_b = spec, B, d, cap_b
+        self.F = len(spec.vocab)
+        self.with_emb, self.with_lr = with_emb, with_lr
+        self.local_off = [0]
+        for v in spec.local_vocab[:-1]:
+            self.local_off.append(self.local_off[-1] + v)
+        self.own_grad = None
+        self.own_grad1 = None
+
+    # requester ---------------------------------------------------------------------------------
+    def sort_batch(self, idx):
+        F, B = idx.shape
+        self.seg_keys, self.entry_seg = [], torch.full((F, B), -1, dtype=torch.int64)
+        for f in range(F):
+            k = idx[f]
+            valid = (k > 0) & (k < self.spec.vocab[f])
+            uniq, inv = torch.unique(k[valid], sorted=True, return_inverse=True)
+            self.seg_keys.append(uniq)
+            self.entry_seg[f, valid] = inv
+
+    def route(self, send_idx, route, overflow):
+        N, cap_b = self.spec.N, self.cap_b
+        send_idx.zero_()
+        route.fill_(-1)
+        for f in range(self.F):
+            keys = self.seg_keys[f]
+            for o in range(N):
+                sel = (keys % N == o).nonzero().view(-1)
+                tot = sel.numel()
+                if tot > cap_b:
+                    overflow.fill_(1)
+                n = min(tot, cap_b)
+                send_idx[o, f, 0] = n
+                send_idx[o, f, 1:1 + n] = keys[sel[:n]] // N + 1
+                route[f, sel[:n]] = (o * cap_b + torch.arange(n)).to(route.dtype)
+
+    def expand(self, route, rows, rows1, emb, lr1):
+        F, B, cap_b = self.F, self.B, self.cap_b
+        for f in range(F):
+            for b in range(B):
+                u = int(self.entry_seg[f, b])
+                code = int(route[f, u]) if u >= 0 else -1
+                if code >= 0:
+                    o, r = divmod(code, cap_b)
+                    if emb is not None:
+                        emb[b * F + f] = rows[o, f, r]
+                    if lr1 is not None:
+                        lr1[b * F + f] = rows1[o, f, r]
+                else:
+                    if emb is not None:
+                        emb[b * F + f] = 0
+                    if lr1 is not None:
+                        lr1[b * F + f] = 0
+
+    def reduce_local(self, gout, dfm, S, emb, dlr):
+        """One gradient per distinct key.  Per-entry gradient of (b, f): gout[b*F+f] (+ the FM term
+        dfm[b] * (S[b] - emb[b, f])); 1-dim table: dlr[b]."""
+        F, B, d = self.F, self.B, self.d
+        self.rowgrad = torch.zeros(F, B, d)
+        self.rowgrad1 = torch.zeros(F, B)
+        for f in range(F):
+            for b in range(B):
+                u = int(self.entry_seg[f, b])
+                if u < 0:
+                    continue
+                if gout is not None or dfm is not None:
+                    g = torch.zeros(d)
+                    if gout is not None:
+                        g = g + gout[b * F + f]
+                    if dfm is not None:
+                        g = g + dfm[b] * (S[b] - emb[b * F + f])
+                    self.rowgrad[f, u] += g
+                if dlr is not None:
+                    self.rowgrad1[f, u] += dlr[b]
+
+    def pack(self, route, grads, grads1):
+        cap_b = self.cap_b
+        for f in range(self.F):
+            for u in range(self.seg_keys[f].numel()):
+                code = int(route[f, u])
+                if code < 0:
+                    continue
+                o, r = divmod(code, cap_b)
+                if grads is not None:
+                    grads[o, f, r] = self.rowgrad[f, u]
+                if grads1 is not None:
+                    grads1[o, f, r] = self.rowgrad1[f, u]
+
+    # owner -------------------------------------------------------------------------------------
+    def gather(self, recv_idx, table, table1, rows, rows1):
+        for s in range(self.spec.N):
+            for f in range(self.F):
+                n = int(recv_idx[s, f, 0])
+                li = recv_idx[s, f, 1:1 + n] + self.local_off[f]
+                if rows is not None:
+                    rows[s, f, :n] = table[li]
+                if rows1 is not None:
+                    rows1[s, f, :n] = table1[li]
+
+    def merge(self, recv_idx, grads, grads1, partials):
+        """Dense local-table gradients (own_grad, own_grad1) = sum of the N requesters' contributions."""
+        R = sum(self.spec.local_vocab)
+        self.own_grad = torch.zeros(R, self.d)
+        self.own_grad1 = torch.zeros(R)
+        for s in range(self.spec.N):
+            for f in range(self.F):
+                n = int(recv_idx[s, f, 0])
+                li = recv_idx[s, f, 1:1 + n] + self.local_off[f]
+                if grads is not None:
+                    self.own_grad.index_add_(0, li, grads[s, f, :n])
+                if grads1 is not None:
+                    self.own_grad1.index_add_(0, li, grads1[s, f, :n])
+        partials.zero_()
+        partials[0] = (self.own_grad ** 2).sum() + (self.own_grad1 ** 2).sum()
+
+    @property
+    def n_own_partials(self):
+        return 4

@@ -1,0 +1,62 @@
+"""Row-sharded multi-process training against the single-GPU fused step on the union batch.
+
+Two ranks share the one GPU of the test box and exchange through gloo with host staging (RCCL needs one
+GPU per rank); every device kernel of the exchange is the real HIP one."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dist_launch import run_ranks
+from dist_worker import rank_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def single_gpu_reference(kind, optimizer, world):
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd.base_model import random_all
+    vocab = [7, 50, 3, 400, 1000, 23, 5000, 64]
+    batch, d, steps = 256, 8, 3
+    random_all(11)
+    rec = data.criteo_x1_recorder(embedding_dim=d, batch_size=batch * world, vocab_sizes=vocab)
+    kw = dict(optimizer_type=optimizer if optimizer != "Adagrad" else "SGD")
+    if kind == "deepfm":
+        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+    elif kind == "fm":
+        m = models.FM(rec, 1e-2, 0, **kw)
+    elif kind == "lr":
+        m = models.LR(rec, 1e-2, 0, **kw)
+    else:
+        m = models.DNN(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 2 and p.shape[0] in vocab:
+                p[1:].normal_(0, 0.05)
+    m.train()
+    eng = m.use_fused_step(mode="sparse", max_norm=0.05, optimizer_type=optimizer)
+    losses = []
+    for s in range(steps):
+        parts = [rank_batch(r + 10 * s, vocab, batch, zero_every=17) for r in range(world)]
+        idx = torch.cat([p[0] for p in parts], 1).cuda()
+        y = torch.cat([p[1] for p in parts], 0).cuda()
+        losses.append(float(eng.step_tensors(idx, y).item()))
+    return m, losses
+
+
+@pytest.mark.parametrize("kind,optimizer", [("deepfm", "SGD"), ("deepfm", "Adam"), ("fm", "Adagrad"), ("lr", "AdamW"),
+                                            ("dnn", "Adam")])
+def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, tmp_path):
+    world = 2
+    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer], timeout=200)
+    assert codes == [0] * world, "\n".join(outs)
+    got = np.load(tmp_path / "state.npz")
+    m, losses = single_gpu_reference(kind, optimizer, world)
+    # mean loss over the union batch = mean of the ranks' local means (equal batch sizes)
+    lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
+    np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
