@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--distinct-batches", type=int, default=8)
+    p.add_argument("--rehearse-on-one-gpu", type=int, default=0,
+                   help="N>1 only: all ranks share cuda:0 and exchange through gloo with host staging (functional "
+                        "rehearsal of the multi-GPU path on a one-GPU box; the numbers mean nothing)")
     return p.parse_args()
 
 
@@ -109,12 +112,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    device = torch.device("cuda", local)
+    rehearse = bool(args.rehearse_on_one_gpu) and world > 1
+    device = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from recommendsystem_amd import data, ops
     from recommendsystem_amd.prof import KernelTimer
@@ -123,7 +130,7 @@ def main():
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
     if world > 1:
         from recommendsystem_amd.dist import DistributedTrainer
-        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.graph))
+        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.graph), stage_cpu=rehearse)
     else:
         eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
 
@@ -175,7 +182,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

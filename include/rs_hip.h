@@ -112,6 +112,48 @@ int rs_fm_fwd(const float* emb, int B, int F, int d, float* sum_out, float* bi_o
 int rs_fm_bwd(const float* emb, const float* S, const float* dfm, const float* dbi, int B, int F, int d, float* demb,
               rs_stream_t stream);
 
+/* Pairs (i<j) are numbered row-major, p = i*(2F-i-1)/2 + (j-i-1), as the reference's nested loops emit them.
+ * The *_bwd entry points that produce parameter gradients write per-workgroup partial rows
+ * (rows = rs_interact_partial_rows(B)); the caller sums them over rows with rs_colsum_f32. */
+int rs_interact_partial_rows(int B);
+
+/* PNN inner products <e_i,e_j> -> out[B,P]                       (model/PNN/PNN.py:65-77) */
+int rs_pnn_inner_fwd(const float* emb, int B, int F, int d, float* out, rs_stream_t stream);
+int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, rs_stream_t stream);
+/* PNN outer products e_i e_j^T flattened -> out[B,P*d*d]         (model/PNN/PNN.py:80-103) */
+int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, rs_stream_t stream);
+int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, rs_stream_t stream);
+
+/* DCN cross network x_{l+1} = x0 (x_l . w_l) + b_l + x_l, w/bias [L,D]; S[B,L] = x_l . w_l saved for the backward
+ * (model/DCN/DCN.py:48-52, with the bias broadcast over the batch).  partials: [rows, 2*L*D] = [dW | dB]. */
+int rs_dcn_cross_fwd(const float* x0, const float* w, const float* bias, int B, int D, int L, float* out, float* S,
+                     rs_stream_t stream);
+int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
+                     int L, float* dx0, float* partials, int rows, rs_stream_t stream);
+
+/* NFM bi-interaction as the reference writes it: 0.5*((E V)^2 - E^2 V^2), E[B,D], V[D,K], K <= 16
+ * (model/NFM/NFM.py:42-44).  s_out[B,K] = E V is saved for the backward; partials: [rows, D*K] = dV. */
+int rs_nfm_bi_fwd(const float* E, const float* V, int B, int D, int K, float* out, float* s_out, rs_stream_t stream);
+int rs_nfm_bi_bwd(const float* E, const float* V, const float* s, const float* dout, int B, int D, int K, float* dE,
+                  float* partials, int rows, rs_stream_t stream);
+
+/* AFM: pairwise products, attention MLP (W[A,d], bA[A], h[A]), softmax over the pairs, weighted pooling and the
+ * projection (pw[d], pb[1]) -> out[B]                             (model/AFM/AFM.py:19-24,36-42,47-56).
+ * d in {4,8,16,32}; backward additionally needs A in {4,8,16} and A*d <= 256.
+ * partials: [rows, A*d + 2A + d + 1] = [dW | dbA | dh | dpw | dpb]. */
+int rs_afm_fwd(const float* emb, int B, int F, int d, int A, const float* W, const float* bA, const float* h,
+               const float* pw, const float* pb, float* out, rs_stream_t stream);
+int rs_afm_bwd(const float* emb, const float* dout, int B, int F, int d, int A, const float* W, const float* bA,
+               const float* h, const float* pw, float* demb, float* partials, int rows, rs_stream_t stream);
+
+/* FFM with one field-aware table per (feature, partner field), stored as T[sum V_f, F*d]; idx [F,B] columnar
+ * (model/FFM/FFM.py:43-62; the reference aliases the F tables of a feature, this takes them independent).
+ * rs_ffm_bwd writes the dense gradient dT (caller-zeroed) using the rs_sparse_bwd_sort plan of the same idx. */
+int rs_ffm_fwd(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* T, int B, int F, int d,
+               float* out, int* err_flag, rs_stream_t stream);
+int rs_ffm_bwd(const int* plan, const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* T,
+               const float* dout, int B, int F, int cap, int d, float* dT, rs_stream_t stream);
+
 /* ---- K3: deterministic sparse embedding backward + optimizer (BaseModel.py:141-150) ---------- */
 /* plan: int32 scratch of rs_sort_plan_ints(F, cap) elements.  Per field, `nsrc` sub-lists of keys are
  * concatenated (a columnar [F,B] batch is nsrc=1, sub_off[f]=f*B, sub_cnt[f]=B, pay_base[f]=f,

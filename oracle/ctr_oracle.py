@@ -94,17 +94,20 @@ def _pairs(n: int):
     return [(i, j) for i in range(n) for j in range(i + 1, n)]
 
 
-def ffm_interaction(ff_tables: Sequence[Sequence[torch.Tensor]], x: torch.Tensor) -> torch.Tensor:
+def ffm_interaction(ff_tables: Sequence[Sequence[torch.Tensor]], x: torch.Tensor,
+                    padding_idx: Optional[int] = None) -> torch.Tensor:
     """model/FFM/FFM.py:43-62 with independent tables.
 
     ``ff_tables[i][j]`` is the table of feature i as seen by field j, (V_i, d);
     x is (B, F) long.  Accumulates pair by pair in (i, j) row-major order.
+    padding_idx: the lookups are nn.Embedding modules in the reference; with the padding_idx=0 of
+    model/utils/Layers.py:132 that row receives no gradient.
     """
     bs, nf = x.shape
     out = torch.zeros(bs, 1)
     for i, j in _pairs(nf):
-        vi_fj = ff_tables[i][j][x[:, i]]
-        vj_fi = ff_tables[j][i][x[:, j]]
+        vi_fj = F.embedding(x[:, i], ff_tables[i][j], padding_idx=padding_idx)
+        vj_fi = F.embedding(x[:, j], ff_tables[j][i], padding_idx=padding_idx)
         out = out + (vi_fj * vj_fi).sum(dim=-1, keepdim=True)
     return out
 
@@ -229,7 +232,8 @@ class OracleMLPBlock(nn.Module):
 class OracleCTRModel(nn.Module):
     """Per-field nn.Embedding tables + one of the reference's model heads.
 
-    kind: "lr" | "fm" | "deepfm" | "dnn" | "widedeep".  Outputs LOGITS (B, 1);
+    kind: "lr" | "fm" | "deepfm" | "dnn" | "widedeep" | "ffm" | "pnn" | "nfm" | "afm" | "dcn".
+    Outputs LOGITS (B, 1);
     the training step applies sigmoid before BCE the way model/LR/LR.py:29-33
     does.  Embedding tables follow model/utils/Layers.py:118-135 (one
     nn.Embedding(V, d, padding_idx=0) and one nn.Embedding(V, 1, padding_idx=0)
@@ -237,9 +241,11 @@ class OracleCTRModel(nn.Module):
     """
 
     def __init__(self, kind, feature_map, features, dim, hidden=(), activation="ReLU",
-                 normalization=None, init_std=1e-4, mirror_unused=False):
+                 normalization=None, init_std=1e-4, mirror_unused=False, pnn_type="inner", nfm_hidden_dim=4,
+                 attention_dim=8, cross_layers_num=3):
         super().__init__()
         self.kind = kind
+        self.pnn_type = pnn_type
         self.cols = categorical_columns(feature_map, features)
         self.dim = dim
         self.emb = nn.ModuleDict()
@@ -274,6 +280,44 @@ class OracleCTRModel(nn.Module):
                     nn.init.xavier_normal_(m.weight)
                     m.bias.data.fill_(0)
 
+        nf, D = len(self.cols), len(self.cols) * dim
+
+        def stack(dims):
+            blocks = nn.Sequential(*[OracleMLPBlock(dims[i], dims[i + 1], activation, normalization)
+                                     for i in range(len(dims) - 1)])
+            for m in blocks.modules():
+                if type(m) is nn.Linear:
+                    nn.init.xavier_normal_(m.weight)
+                    m.bias.data.fill_(0)
+            return blocks
+
+        if kind == "ffm":                           # model/FFM/FFM.py:21-23 with independent tables
+            self.ffm = nn.ModuleDict()
+            for c in self.cols:
+                e = nn.Embedding(feature_map[c]["vocab_size"], nf * dim, padding_idx=0)
+                with torch.no_grad():
+                    e.weight[1:].normal_(0, init_std)
+                self.ffm[c] = e
+        elif kind == "pnn":                         # model/PNN/PNN.py:19-40
+            pairs = nf * (nf - 1) // 2
+            pnn_dim = {"inner": pairs, "outer": pairs * dim * dim, "both": pairs + pairs * dim * dim}[pnn_type]
+            self.deep = stack([D + pnn_dim] + list(hidden) + [1])
+        elif kind == "nfm":                         # model/NFM/NFM.py:16-33
+            self.v = nn.Parameter(torch.randn(D, nfm_hidden_dim))
+            self.linear = nn.Linear(nf, 1)
+            nn.init.xavier_normal_(self.linear.weight)
+            self.linear.bias.data.fill_(0)
+            self.deep = stack([nfm_hidden_dim] + list(hidden) + [1])
+        elif kind == "afm":                         # model/AFM/AFM.py:19-26
+            self.attention = nn.Sequential(nn.Linear(dim, attention_dim), nn.ReLU(),
+                                           nn.Linear(attention_dim, 1, bias=False), nn.Softmax(dim=1))
+            self.p = nn.Linear(dim, 1)
+        elif kind == "dcn":                         # model/DCN/DCN.py:16-31
+            self.cross_w = nn.ParameterList([nn.Parameter(torch.randn(D, 1)) for _ in range(cross_layers_num)])
+            self.cross_b = nn.ParameterList([nn.Parameter(torch.randn(D, 1)) for _ in range(cross_layers_num)])
+            self.deep = stack([D] + list(hidden))
+            self.fc = nn.Linear(D + list(hidden)[-1], 1)
+
     def embed(self, x):
         return torch.stack([self.emb[c](x[c].long()) for c in self.cols], dim=1)
 
@@ -292,6 +336,30 @@ class OracleCTRModel(nn.Module):
             return self.deep(e)
         if self.kind == "widedeep":                 # model/WideDeep/WideDeep.py:43-51
             return self.lr(x) + self.deep(e)
+        B, nf, d = e.shape
+        if self.kind == "ffm":                      # model/FFM/FFM.py:32-40
+            xm = torch.stack([x[c].long() for c in self.cols], dim=1)
+            tabs = [[self.ffm[c].weight[:, j * d:(j + 1) * d] for j in range(nf)] for c in self.cols]
+            return self.lr(x) + ffm_interaction(tabs, xm, padding_idx=0)
+        if self.kind == "pnn":                      # model/PNN/PNN.py:45-60
+            flat = e.view(B, -1)
+            parts = []
+            if self.pnn_type in ("inner", "both"):
+                parts.append(pnn_inner(flat, nf, d))
+            if self.pnn_type in ("outer", "both"):
+                parts.append(pnn_outer(flat, nf, d))
+            return self.deep(torch.cat([flat] + parts, dim=1))
+        if self.kind == "nfm":                      # model/NFM/NFM.py:37-49
+            xm = torch.stack([x[c].long() for c in self.cols], dim=1)
+            return self.linear(xm.float()) + self.deep(nfm_bi_interaction_reference(e.view(B, -1), self.v))
+        if self.kind == "afm":                      # model/AFM/AFM.py:32-45
+            pw = afm_pairwise(e)
+            att = self.attention(pw)
+            return self.lr(x) + self.p(torch.sum(att * pw, dim=1))
+        if self.kind == "dcn":                      # model/DCN/DCN.py:35-52 (bias broadcast over the batch)
+            flat = e.view(B, -1)
+            cross = dcn_cross(flat, list(self.cross_w), [b.view(-1) for b in self.cross_b])
+            return self.fc(torch.cat([cross, self.deep(e)], dim=1))
         raise ValueError(self.kind)
 
 

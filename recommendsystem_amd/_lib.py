@@ -67,6 +67,18 @@ _SIGS = {
     # interact.hip
     "rs_fm_fwd": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_fm_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_inner_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_inner_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_outer_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_outer_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_dcn_cross_fwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
+    "rs_dcn_cross_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
+    "rs_nfm_bi_fwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
+    "rs_nfm_bi_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
+    "rs_afm_fwd": [c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_afm_bwd": [c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, c_stream],
+    "rs_ffm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, I, I, I, c_f32p, c_i32p, c_stream],
+    "rs_ffm_bwd": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_stream],
 }
 # entry points that do not follow the "returns int status" convention: name -> (restype, argtypes)
 _PLAIN = {
@@ -81,6 +93,7 @@ _PLAIN = {
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),
     "rs_act_bwd_num_partials": (I, [L]),
+    "rs_interact_partial_rows": (I, [I]),
 }
 
 _lib = None

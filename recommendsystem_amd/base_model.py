@@ -126,7 +126,8 @@ class BaseModel(nn.Module):
     def reset_parameters(self):
         """BaseModel.py:79-91: Xavier-normal nn.Linear weights, zero biases, then custom hooks."""
         def reset_default_params(m):
-            if type(m) in [nn.Linear, nn.Conv1d]:
+            # exact types as in the reference, plus this package's HIP-backed nn.Linear subclass
+            if type(m) in [nn.Linear, nn.Conv1d] or (isinstance(m, nn.Linear) and type(m).__name__ == "Linear"):
                 nn.init.xavier_normal_(m.weight)
                 if m.bias is not None:
                     m.bias.data.fill_(0)

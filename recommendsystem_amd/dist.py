@@ -317,15 +317,17 @@ class DistributedTrainer(FusedTrainer):
         ex.backward(gout, dz if self.has_fm else None, ctx["S"],
                     ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
                     ex.own_partials)
-        # ||g||^2 of the owned rows, summed over ranks (every rank owns disjoint rows)
-        ops.colsum(ex.own_partials.view(-1, 1), out=ex.sq)
-        self.comm.all_reduce(ex.sq)
-        P = plan.partials
-        P[:plan.n_partials].zero_()
-        P[0:1].copy_(ex.sq)
+        # ||g||^2 of the owned rows (every rank owns disjoint rows) rides behind the dense gradients in the
+        # one all-reduce of the step
+        ops.colsum(ex.own_partials.view(-1, 1), out=self.flat_g_ext[-4:-3])
+        self._cur_plan = plan
 
     def _reduce_dense_grads(self):
-        self.comm.all_reduce(self.flat_g)
+        self.comm.all_reduce(self.flat_g_ext)
+        plan = self._cur_plan
+        P = plan.partials
+        P[:plan.n_partials].zero_()
+        P[0:1].copy_(self.flat_g_ext[-4:-3])
 
     def _embed_update(self, plan):
         # `plan` is the base class's per-batch-size plan (its partial buffer carries the norm); the update

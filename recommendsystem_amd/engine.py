@@ -156,7 +156,10 @@ class FusedTrainer:
             offs.append(o)
             o += (p.numel() + 3) // 4 * 4
         self.flat_w = torch.zeros(max(o, 4), dtype=torch.float32, device=self.device)
-        self.flat_g = torch.zeros_like(self.flat_w)
+        # four spare floats behind the gradients: the multi-GPU trainer sends its scalar reductions along
+        # with the one all-reduce of this buffer
+        self.flat_g_ext = torch.zeros(self.flat_w.numel() + 4, dtype=torch.float32, device=self.device)
+        self.flat_g = self.flat_g_ext[:self.flat_w.numel()]
         self.gviews = {}
         with torch.no_grad():
             for p, off in zip(ps, offs):
@@ -379,9 +382,9 @@ class FusedTrainer:
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
         # ---- L2 terms, global norm, clip coefficient ------------------------------------------
+        self._reduce_dense_grads()
         if self.net_reg:
             ops.axpy(self.net_reg, self.flat_w, self.flat_g)
-        self._reduce_dense_grads()
         dense_p = P[n_sp:n_sp + N_DENSE_PARTIALS]
         ops.sumsq_partials(self.flat_g, dense_p)
         if self.mode == "sparse":

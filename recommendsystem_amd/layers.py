@@ -166,6 +166,17 @@ class LinearRegression_layer(nn.Module):
         return Fn.lr_forward(idx, tab1, self.bias, tab1.weights())
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters and state_dict keys) whose forward and backward run on the HIP GEMM;
+    used where the reference's models hold a bare nn.Linear (model/DCN/DCN.py:31, model/NFM/NFM.py:18)."""
+
+    def forward(self, x):
+        x2d = x.reshape(x.shape[0], -1).contiguous()
+        if not x2d.is_cuda:
+            raise RSError("Linear: input is on the CPU (this package has no CPU path)")
+        return Fn.mlp_block(x2d, self.weight, self.bias, 0, None, None, None, None, self.training, None, None)
+
+
 def _activation_module(name: str):
     name = name.lower()
     if name == "relu":

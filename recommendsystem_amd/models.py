@@ -15,7 +15,8 @@ from torch import nn
 
 from . import functional as Fn
 from .base_model import BaseModel
-from .layers import LinearRegression_layer, MLPBlock, ResidualMLPBlock
+from . import interactions as X
+from .layers import Linear, LinearRegression_layer, MLPBlock, ResidualMLPBlock
 
 
 def _mlp_stack(input_dim, hidden_dim_list, activation_func, normalization, dropout_rate, head=True, block=MLPBlock):
@@ -161,3 +162,133 @@ class DeepCrossing(_CTRModel):
     def logits(self, x):
         x = self.features_to_divice(x)
         return self.mlp(self.embedding_layer(x))
+
+
+class FFM(_CTRModel):
+    """model/FFM/FFM.py:32-62 with one independent table per (feature, partner field): LR + sum_{i<j}
+    <v_{i,f_j}, v_{j,f_i}>."""
+    KIND = "ffm"
+
+    def __init__(self, dataRecorder, lr, gpu, regular=None, optimizer_type="AdamW", **kw):
+        super().__init__("FFM", dataRecorder, lr, gpu, regular, optimizer_type=optimizer_type, **kw)
+        self.linear = LinearRegression_layer(self.dataRecorder)
+        self.field_aware = X.FieldAwareTables(self.dataRecorder.feature_map, self.embedding_layer.lookup_columns,
+                                              self.dataRecorder.embedding_dim)
+        self._finish()
+
+    def logits(self, x):
+        x = self.features_to_divice(x)
+        idx = self.embedding_layer.index_matrix(x)
+        return self.linear(x) + self.field_aware(idx)
+
+
+class PNN(_CTRModel):
+    """model/PNN/PNN.py:19-60: MLP over [embeddings | inner and/or outer products of all field pairs]."""
+    KIND = "pnn"
+
+    def __init__(self, dataRecorder, lr, gpu, hidden_dim_list=(1024, 512, 256), pnn_type="inner", activation_func="ReLU",
+                 normalization="bn", dropout_rate=0, regular=None, **kw):
+        super().__init__("PNN", dataRecorder, lr, gpu, regular, **kw)
+        nf, d = self.embedded_field_count(), self.dataRecorder.embedding_dim
+        pairs = nf * (nf - 1) // 2
+        if pnn_type == "inner":
+            pnn_dim = pairs
+        elif pnn_type == "outer":
+            pnn_dim = pairs * d * d
+        elif pnn_type == "both":
+            pnn_dim = pairs + pairs * d * d
+        else:
+            raise ValueError("pnn_type must be either 'inner' or 'outer' or 'both")
+        self.pnn_type = pnn_type
+        self.mlp = _mlp_stack(nf * d + pnn_dim, list(hidden_dim_list), activation_func, normalization, dropout_rate)
+        self._finish()
+
+    def inner_product(self, emb_out):
+        return X.pnn_inner(emb_out)
+
+    def outer_product(self, emb_out):
+        return X.pnn_outer(emb_out)
+
+    def both_product(self, emb_out):
+        return torch.cat([X.pnn_inner(emb_out), X.pnn_outer(emb_out)], dim=1)
+
+    def logits(self, x):
+        x = self.features_to_divice(x)
+        emb_out = self.embedding_layer(x)
+        pnn_output = {"inner": self.inner_product, "outer": self.outer_product, "both": self.both_product}[self.pnn_type](
+            emb_out)
+        return self.mlp(torch.cat([emb_out.view(emb_out.shape[0], -1), pnn_output], dim=1))
+
+
+class NFM(_CTRModel):
+    """model/NFM/NFM.py:16-49 as written: a Linear over the raw (float) index values, the
+    0.5*((E v)^2 - E^2 v^2) pooling with v ~ randn(F*d, k), then the MLP."""
+    KIND = "nfm"
+
+    def __init__(self, dataRecorder, lr, gpu, hidden_dim_list=(1024, 512, 256), hidden_dim=4, activation_func="ReLU",
+                 normalization="bn", dropout_rate=0, regular=None, **kw):
+        super().__init__("NFM", dataRecorder, lr, gpu, regular, **kw)
+        nf, d = self.embedded_field_count(), self.dataRecorder.embedding_dim
+        self.hidden_dim = hidden_dim
+        self.v = nn.Parameter(torch.randn(nf * d, hidden_dim))
+        self.linear = Linear(nf, 1)
+        self.deep = _mlp_stack(hidden_dim, list(hidden_dim_list), activation_func, normalization, dropout_rate)
+        self._finish()
+
+    def logits(self, x):
+        x = self.features_to_divice(x)
+        idx = self.embedding_layer.index_matrix(x)
+        first_order_output = self.linear(idx.t().float())
+        emb_out = self.embedding_layer(x)
+        second_order_output = X.nfm_bi_interaction(emb_out, self.v)
+        return first_order_output + self.deep(second_order_output)
+
+
+class AFM(_CTRModel):
+    """model/AFM/AFM.py:19-45: LR + p(sum_pairs softmax(attention(e_i*e_j)) e_i*e_j)."""
+    KIND = "afm"
+
+    def __init__(self, dataRecorder, lr, gpu, attention_dim=8, regular=None, **kw):
+        super().__init__("AFM", dataRecorder, lr, gpu, regular, **kw)
+        self.attention_dim = attention_dim
+        self.linear = LinearRegression_layer(self.dataRecorder)
+        self.pool = X.AttentionPooling(self.dataRecorder.embedding_dim, attention_dim)
+        self._finish()
+
+    # the reference registers `attention` and `p` on the model itself: keep those names reachable
+    @property
+    def attention(self):
+        return self.pool.attention
+
+    @property
+    def p(self):
+        return self.pool.p
+
+    def logits(self, x):
+        x = self.features_to_divice(x)
+        return self.linear(x) + self.pool(self.embedding_layer(x))
+
+
+class DCN(_CTRModel):
+    """model/DCN/DCN.py:16-52: cross network and MLP side by side on the flattened embeddings, then
+    Linear(D + h_last, 1)."""
+    KIND = "dcn"
+
+    def __init__(self, dataRecorder, lr, gpu, hidden_dim_list=(1024, 512, 256), cross_layers_num=3, activation_func="ReLU",
+                 normalization="bn", dropout_rate=0, regular=None, **kw):
+        super().__init__("DCN", dataRecorder, lr, gpu, regular, **kw)
+        D = self.embedded_field_count() * self.dataRecorder.embedding_dim
+        self.cross = X.CrossNetwork(D, cross_layers_num)
+        self.deep = _mlp_stack(D, list(hidden_dim_list), activation_func, normalization, dropout_rate, head=False)
+        self.fc = Linear(D + hidden_dim_list[-1], 1)
+        self._finish()
+
+    def crossing_network(self, emb_out):
+        return self.cross(emb_out)
+
+    def logits(self, x):
+        x = self.features_to_divice(x)
+        emb_out = self.embedding_layer(x)
+        cross_output = self.crossing_network(emb_out)
+        deep_output = self.deep(emb_out)
+        return self.fc(torch.cat([cross_output, deep_output], dim=1))

@@ -494,6 +494,148 @@ def fm_bwd(emb, S, dfm=None, dbi=None):
     return demb
 
 
+def interact_partial_rows(B: int) -> int:
+    return _lib.lib().rs_interact_partial_rows(int(B))
+
+
+def pnn_inner_fwd(emb: torch.Tensor) -> torch.Tensor:
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    out = torch.empty((B, Fn * (Fn - 1) // 2), dtype=torch.float32, device=emb.device)
+    call("rs_pnn_inner_fwd", ptr(emb), B, Fn, d, ptr(out), stream())
+    return out
+
+
+def pnn_inner_bwd(emb: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    B, Fn, d = emb.shape
+    _chk(dout, torch.float32, "dout", (B, Fn * (Fn - 1) // 2))
+    demb = torch.empty_like(emb)
+    call("rs_pnn_inner_bwd", ptr(emb), ptr(dout), B, Fn, d, ptr(demb), stream())
+    return demb
+
+
+def pnn_outer_fwd(emb: torch.Tensor) -> torch.Tensor:
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    out = torch.empty((B, Fn * (Fn - 1) // 2 * d * d), dtype=torch.float32, device=emb.device)
+    call("rs_pnn_outer_fwd", ptr(emb), B, Fn, d, ptr(out), stream())
+    return out
+
+
+def pnn_outer_bwd(emb: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    B, Fn, d = emb.shape
+    _chk(dout, torch.float32, "dout", (B, Fn * (Fn - 1) // 2 * d * d))
+    demb = torch.empty_like(emb)
+    call("rs_pnn_outer_bwd", ptr(emb), ptr(dout), B, Fn, d, ptr(demb), stream())
+    return demb
+
+
+def dcn_cross_fwd(x0: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
+    """x0 [B,D]; w, bias [L,D] -> (out [B,D], S [B,L])."""
+    _chk(x0, torch.float32, "x0")
+    B, D = x0.shape
+    L = w.shape[0]
+    _chk(w, torch.float32, "w", (L, D))
+    _chk(bias, torch.float32, "bias", (L, D))
+    out = torch.empty_like(x0)
+    S = torch.empty((B, L), dtype=torch.float32, device=x0.device)
+    call("rs_dcn_cross_fwd", ptr(x0), ptr(w), ptr(bias), B, D, L, ptr(out), ptr(S), stream())
+    return out, S
+
+
+def dcn_cross_bwd(x0, S, dout, w, bias):
+    """-> (dx0 [B,D], dW [L,D], dB [L,D])."""
+    B, D = x0.shape
+    L = w.shape[0]
+    _chk(dout, torch.float32, "dout", (B, D))
+    rows = interact_partial_rows(B)
+    dx0 = torch.empty_like(x0)
+    part = torch.empty((rows, 2 * L * D), dtype=torch.float32, device=x0.device)
+    call("rs_dcn_cross_bwd", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx0), ptr(part), rows, stream())
+    g = colsum(part)
+    return dx0, g[:L * D].view(L, D), g[L * D:].view(L, D)
+
+
+def nfm_bi_fwd(E: torch.Tensor, V: torch.Tensor):
+    """E [B,D], V [D,K] -> (out [B,K], s [B,K])."""
+    _chk(E, torch.float32, "E")
+    B, D = E.shape
+    K = V.shape[1]
+    _chk(V, torch.float32, "V", (D, K))
+    out = torch.empty((B, K), dtype=torch.float32, device=E.device)
+    s = torch.empty_like(out)
+    call("rs_nfm_bi_fwd", ptr(E), ptr(V), B, D, K, ptr(out), ptr(s), stream())
+    return out, s
+
+
+def nfm_bi_bwd(E, V, s, dout):
+    B, D = E.shape
+    K = V.shape[1]
+    _chk(dout, torch.float32, "dout", (B, K))
+    rows = interact_partial_rows(B)
+    dE = torch.empty_like(E)
+    part = torch.empty((rows, D * K), dtype=torch.float32, device=E.device)
+    call("rs_nfm_bi_bwd", ptr(E), ptr(V), ptr(s), ptr(dout), B, D, K, ptr(dE), ptr(part), rows, stream())
+    return dE, colsum(part).view(D, K)
+
+
+def afm_fwd(emb, W, bA, h, pw, pb) -> torch.Tensor:
+    """emb [B,F,d]; W [A,d], bA [A], h [A] (or [1,A]), pw [d] (or [1,d]), pb [1] -> out [B]."""
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    A = W.shape[0]
+    _chk(W, torch.float32, "W", (A, d))
+    for t, n, k in ((bA, "bA", A), (h, "h", A), (pw, "pw", d), (pb, "pb", 1)):
+        _chk(t, torch.float32, n)
+        if t.numel() != k:
+            raise RSError(f"afm: {n} must have {k} elements")
+    out = torch.empty((B,), dtype=torch.float32, device=emb.device)
+    call("rs_afm_fwd", ptr(emb), B, Fn, d, A, ptr(W), ptr(bA), ptr(h), ptr(pw), ptr(pb), ptr(out), stream())
+    return out
+
+
+def afm_bwd(emb, dout, W, bA, h, pw):
+    """-> (demb, dW [A,d], dbA [A], dh [A], dpw [d], dpb [1])."""
+    B, Fn, d = emb.shape
+    A = W.shape[0]
+    _chk(dout, torch.float32, "dout", (B,))
+    rows = interact_partial_rows(B)
+    np_ = A * d + 2 * A + d + 1
+    demb = torch.empty_like(emb)
+    part = torch.empty((rows, np_), dtype=torch.float32, device=emb.device)
+    call("rs_afm_bwd", ptr(emb), ptr(dout), B, Fn, d, A, ptr(W), ptr(bA), ptr(h), ptr(pw), ptr(demb), ptr(part), rows,
+         stream())
+    g = colsum(part)
+    o = A * d
+    return demb, g[:o].view(A, d), g[o:o + A], g[o + A:o + 2 * A], g[o + 2 * A:o + 2 * A + d], g[o + 2 * A + d:]
+
+
+def ffm_fwd(idx: torch.Tensor, layout: FieldLayout, T: torch.Tensor) -> torch.Tensor:
+    """idx [F,B] int64; T [sum V_f, F*d] -> out [B]."""
+    Fn, B = idx.shape
+    _chk(idx, torch.int64, "idx", (layout.num_fields, B))
+    _chk(T, torch.float32, "T")
+    if T.shape[0] != layout.total_rows or T.shape[1] % Fn:
+        raise RSError("ffm: table must be [sum vocab, F*d]")
+    d = T.shape[1] // Fn
+    out = torch.empty((B,), dtype=torch.float32, device=idx.device)
+    call("rs_ffm_fwd", ptr(idx), ptr(layout.row_offset_t), ptr(layout.vocab_t), ptr(T), B, Fn, d, ptr(out),
+         ptr(layout.err_flag), stream())
+    return out
+
+
+def ffm_bwd(plan: "SparsePlan", idx: torch.Tensor, T: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    """Dense gradient of T; `plan` is a SparsePlan of the same layout (it is re-sorted here)."""
+    Fn, B = idx.shape
+    d = T.shape[1] // Fn
+    _chk(dout, torch.float32, "dout", (B,))
+    plan.sort_columnar(idx)
+    dT = torch.zeros_like(T)
+    call("rs_ffm_bwd", ptr(plan.plan), ptr(idx), ptr(plan.layout.row_offset_t), ptr(plan.layout.vocab_t), ptr(T), ptr(dout),
+         B, Fn, plan.cap, d, ptr(dT), stream())
+    return dT
+
+
 def axpy(a: float, x: torch.Tensor, y: torch.Tensor):
     """y += a * x (flat)."""
     _chk(x, torch.float32, "x")

@@ -1,0 +1,231 @@
+"""K2 parity: feature-interaction kernels (PNN inner/outer, DCN cross, NFM, AFM, FFM) forward and backward
+against the CPU oracle (oracle/ctr_oracle.py, autograd for the gradients) and against the vectors captured
+from the reference's own methods (tests/golden/interactions.npz).  Tolerance: 1e-5 relative on fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ctr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+DEV = "cuda:0"
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, msg=""):
+    torch.testing.assert_close(a.detach().cpu(), b.detach().cpu(), rtol=rtol, atol=atol, msg=lambda s: f"{msg}: {s}")
+
+
+def G(name):
+    return torch.from_numpy(load_golden("interactions.npz")[name])
+
+
+SHAPES = [(1, 2, 4), (6, 5, 4), (33, 7, 8), (64, 26, 16), (130, 39, 16), (9, 3, 3), (5, 70, 4), (17, 4, 32)]
+
+
+# ---------------------------------------------------------------- golden vectors (reference outputs)
+def test_golden_pnn():
+    from recommendsystem_amd import ops
+    emb = G("emb").to(DEV)
+    close(ops.pnn_inner_fwd(emb), G("pnn_inner"))
+    close(ops.pnn_outer_fwd(emb), G("pnn_outer"))
+
+
+def test_golden_dcn():
+    from recommendsystem_amd import ops
+    g = load_golden("interactions.npz")
+    x0 = torch.from_numpy(g["emb"]).reshape(6, -1).to(DEV)
+    w = torch.cat([torch.from_numpy(g[f"dcn.w.{l}"]).view(1, -1) for l in range(3)]).to(DEV)
+    b = torch.cat([torch.from_numpy(g[f"dcn.b.{l}"]).view(1, -1) for l in range(3)]).to(DEV)
+    out, _ = ops.dcn_cross_fwd(x0, w, b)
+    close(out, G("dcn_out"), rtol=2e-5, atol=1e-5)
+
+
+def test_golden_nfm():
+    from recommendsystem_amd import ops
+    E = G("emb").reshape(6, -1).to(DEV)
+    out, _ = ops.nfm_bi_fwd(E, G("nfm_v").to(DEV))
+    close(out, G("nfm_bi"), rtol=2e-5, atol=1e-5)
+
+
+def test_golden_afm():
+    from recommendsystem_amd import ops
+    out = ops.afm_fwd(G("afm_emb").to(DEV), G("afm.att_w").to(DEV), G("afm.att_b").to(DEV), G("afm.att_h").to(DEV),
+                      G("afm.p_w").to(DEV), G("afm.p_b").to(DEV))
+    close(torch.sigmoid(G("lr").to(DEV) + out.view(-1, 1)), G("afm_out"))       # the fixture is sigmoid(lr + afm term)
+
+
+def test_golden_ffm():
+    from recommendsystem_amd import ops
+    g = load_golden("interactions.npz")
+    Fn, d, V = 5, 4, 9
+    # T[row of feature i value x][j*d:(j+1)*d] = table_{i,j}[x]
+    T = torch.cat([torch.cat([torch.from_numpy(g[f"ffm.table.{i}.{j}"]) for j in range(Fn)], 1) for i in range(Fn)], 0)
+    layout = ops.FieldLayout([V] * Fn, DEV)
+    idx = torch.from_numpy(g["xi"]).t().contiguous().to(DEV)
+    close(ops.ffm_fwd(idx, layout, T.to(DEV)).view(-1, 1), G("ffm_out"))
+    layout.check_indices()
+
+
+# ---------------------------------------------------------------- oracle, forward + backward
+@pytest.mark.parametrize("B,Fn,d", SHAPES)
+def test_pnn_inner(B, Fn, d):
+    from recommendsystem_amd import interactions as X
+    g = torch.Generator().manual_seed(B * 100 + Fn)
+    emb = torch.randn(B, Fn, d, generator=g)
+    e_ref = emb.clone().requires_grad_(True)
+    ref = O.pnn_inner(e_ref.view(B, -1), Fn, d)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    e = emb.to(DEV).requires_grad_(True)
+    out = X.pnn_inner(e)
+    # sums of d (forward) / F (backward) signed products: the absolute floor scales with the terms' magnitude
+    close(out, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()), msg="fwd")
+    out.backward(gout.to(DEV))
+    close(e.grad, e_ref.grad, rtol=1e-5, atol=1e-6 * float(e_ref.grad.abs().max()), msg="demb")
+
+
+@pytest.mark.parametrize("B,Fn,d", [s for s in SHAPES if s[1] * s[1] * s[2] * s[2] < 300000])
+def test_pnn_outer(B, Fn, d):
+    from recommendsystem_amd import interactions as X
+    g = torch.Generator().manual_seed(B * 100 + Fn)
+    emb = torch.randn(B, Fn, d, generator=g)
+    e_ref = emb.clone().requires_grad_(True)
+    ref = O.pnn_outer(e_ref.view(B, -1), Fn, d)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    e = emb.to(DEV).requires_grad_(True)
+    out = X.pnn_outer(e)
+    assert torch.equal(out.cpu(), ref.detach())          # one multiply per element: bit-exact
+    out.backward(gout.to(DEV))
+    close(e.grad, e_ref.grad, rtol=1e-5, atol=1e-6 * float(e_ref.grad.abs().max()), msg="demb")
+
+
+@pytest.mark.parametrize("B,D,L", [(1, 8, 1), (6, 20, 3), (700, 624, 3), (65, 416, 3), (33, 100, 5), (4, 1030, 2)])
+def test_dcn_cross(B, D, L):
+    from recommendsystem_amd import ops
+    from recommendsystem_amd.interactions import _CrossFn
+    g = torch.Generator().manual_seed(B + D)
+    x0 = torch.randn(B, D, generator=g) * 0.3
+    w = torch.randn(L, D, generator=g) * (1.0 / D ** 0.5)
+    b = torch.randn(L, D, generator=g) * 0.1
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x0, w, b))
+    ref = O.dcn_cross(xr, [wr[l] for l in range(L)], [br[l] for l in range(L)])
+    gout = torch.randn(B, D, generator=g)
+    ref.backward(gout)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x0, w, b))
+    out = _CrossFn.apply(xg, wg, bg)
+    close(out, ref, rtol=2e-5, atol=2e-6, msg="fwd")
+    out.backward(gout.to(DEV))
+    close(xg.grad, xr.grad, rtol=5e-5, atol=5e-6, msg="dx0")
+    close(wg.grad, wr.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="dw")
+    close(bg.grad, br.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="db")
+
+
+def test_dcn_module_reference_shapes():
+    """Parameters keep the reference's (D, 1) shapes and names; gradients reach each of them."""
+    from recommendsystem_amd.interactions import CrossNetwork
+    torch.manual_seed(3)
+    net = CrossNetwork(24, 3).to(DEV)
+    assert [tuple(p.shape) for p in net.cross_w] == [(24, 1)] * 3 and [tuple(p.shape) for p in net.cross_b] == [(24, 1)] * 3
+    assert set(net.state_dict()) == {f"cross_{k}.{i}" for k in "wb" for i in range(3)}
+    x = (torch.randn(10, 6, 4) * 0.2).to(DEV).requires_grad_(True)
+    out = net(x)
+    ref = O.dcn_cross(x.detach().cpu().view(10, -1), [p.detach().cpu() for p in net.cross_w],
+                      [p.detach().cpu().view(-1) for p in net.cross_b])
+    close(out, ref, rtol=2e-5, atol=2e-6)
+    out.sum().backward()
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
+
+
+@pytest.mark.parametrize("B,D,K", [(1, 8, 1), (6, 20, 3), (700, 624, 4), (65, 416, 4), (33, 100, 16)])
+def test_nfm_bi(B, D, K):
+    from recommendsystem_amd import interactions as X
+    g = torch.Generator().manual_seed(B + D + K)
+    E = torch.randn(B, D, generator=g) * 0.5
+    V = torch.randn(D, K, generator=g)
+    Er, Vr = E.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    ref = O.nfm_bi_interaction_reference(Er, Vr)
+    gout = torch.randn(B, K, generator=g)
+    ref.backward(gout)
+    Eg, Vg = E.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
+    out = X.nfm_bi_interaction(Eg, Vg)
+    scale = float(ref.abs().max())
+    close(out, ref, rtol=2e-5, atol=2e-6 * max(1.0, scale), msg="fwd")
+    out.backward(gout.to(DEV))
+    close(Eg.grad, Er.grad, rtol=5e-5, atol=1e-5 * max(1.0, float(Er.grad.abs().max())), msg="dE")
+    close(Vg.grad, Vr.grad, rtol=5e-5, atol=1e-5 * max(1.0, float(Vr.grad.abs().max())), msg="dV")
+
+
+@pytest.mark.parametrize("B,Fn,d,A", [(1, 2, 4, 4), (6, 5, 4, 8), (33, 7, 8, 8), (64, 26, 16, 8), (130, 39, 16, 8),
+                                      (600, 39, 16, 16), (5, 70, 4, 4), (17, 4, 32, 8)])
+def test_afm(B, Fn, d, A):
+    from recommendsystem_amd.interactions import _AFMFn
+    g = torch.Generator().manual_seed(B + Fn + d)
+    emb = torch.randn(B, Fn, d, generator=g) * 0.7
+    W = torch.randn(A, d, generator=g) * 0.5
+    bA = torch.randn(A, generator=g) * 0.1
+    h = torch.randn(1, A, generator=g)
+    pw = torch.randn(1, d, generator=g)
+    pb = torch.randn(1, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (emb, W, bA, h, pw, pb)]
+    ref = O.afm_forward(*ref_in)
+    gout = torch.randn(B, 1, generator=g)
+    ref.backward(gout)
+    ins = [t.to(DEV).requires_grad_(True) for t in (emb, W, bA, h, pw, pb)]
+    out = _AFMFn.apply(*ins)
+    close(out, ref, rtol=2e-5, atol=2e-6, msg="fwd")
+    out.backward(gout.to(DEV))
+    for name, a, r in zip(("demb", "dW", "dbA", "dh", "dpw", "dpb"), ins, ref_in):
+        tol = 1e-5 * max(1.0, float(r.grad.abs().max()))
+        close(a.grad, r.grad, rtol=1e-4, atol=tol, msg=name)
+
+
+def test_afm_module_keeps_reference_names():
+    from recommendsystem_amd.interactions import AttentionPooling
+    m = AttentionPooling(8, 4)
+    assert set(m.state_dict()) == {"attention.0.weight", "attention.0.bias", "attention.2.weight", "p.weight", "p.bias"}
+
+
+@pytest.mark.parametrize("B,vocabs,d", [(6, [9] * 5, 4), (64, [11, 7, 50, 3, 200], 8), (300, [100] * 26, 16),
+                                        (257, [10] * 13 + [int(10 ** (1 + 3 * i / 25)) for i in range(26)], 16),
+                                        (3, [5, 6], 3)])
+def test_ffm(B, vocabs, d):
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(B + d)
+    Fn = len(vocabs)
+    tabs = [[torch.randn(v, d, generator=g) * 0.3 for _ in range(Fn)] for v in vocabs]
+    # hot keys and padding entries
+    x = torch.stack([(torch.rand(B, generator=g) ** 3 * v).long().clamp(0, v - 1) for v in vocabs], 1)
+    ref_tabs = [[t.clone().requires_grad_(True) for t in row] for row in tabs]
+    ref = O.ffm_interaction(ref_tabs, x)
+    gout = torch.randn(B, 1, generator=g)
+    ref.backward(gout)
+    T = torch.cat([torch.cat(row, 1) for row in tabs], 0).to(DEV)
+    layout = ops.FieldLayout(vocabs, DEV)
+    idx = x.t().contiguous().to(DEV)
+    out = ops.ffm_fwd(idx, layout, T)
+    close(out.view(-1, 1), ref, rtol=2e-5, atol=2e-6 * max(1.0, float(ref.abs().max())), msg="fwd")
+    plan = ops.SparsePlan(layout, cap=B, d=1, with_lr=False)
+    dT = ops.ffm_bwd(plan, idx, T, gout.view(-1).to(DEV))
+    want = torch.cat([torch.cat([t.grad if t.grad is not None else torch.zeros_like(t) for t in row], 1)
+                      for row in ref_tabs], 0)
+    # index 0 is the padding row: the reference's nn.Embedding(padding_idx=0) gives it no gradient
+    o = 0
+    for v in vocabs:
+        want[o] = 0
+        o += v
+    close(dT, want, rtol=2e-5, atol=2e-6 * max(1.0, float(want.abs().max())), msg="dT")
+    layout.check_indices()
+
+
+def test_unsupported_shapes_raise():
+    from recommendsystem_amd import ops
+    from recommendsystem_amd._lib import RSError
+    with pytest.raises(RSError):
+        ops.afm_fwd(torch.zeros(2, 3, 5, device=DEV), torch.zeros(4, 5, device=DEV), torch.zeros(4, device=DEV),
+                    torch.zeros(4, device=DEV), torch.zeros(5, device=DEV), torch.zeros(1, device=DEV))
+    with pytest.raises(RSError):
+        ops.nfm_bi_fwd(torch.zeros(2, 8, device=DEV), torch.zeros(8, 17, device=DEV))
