@@ -62,12 +62,21 @@ int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int
  *   forward  H  = act(X W^T + b)          (a_mc=0, b_nc=0)
  *   dX       dZ'= (dZ W) * act'(H_prev)   (a_mc=0, b_nc=1)
  *   dW       dW = dZ^T X                  (a_mc=1, b_nc=1, split over the batch when splitk > 1)
- * tile < 0 / splitk <= 0: chosen by rs_gemm_plan.  workspace is needed when the split count > 1. */
+ * tile < 0 / splitk <= 0: chosen by rs_gemm_plan.  workspace is needed when the split count > 1.
+ * colsum_part (optional; needs an explicit tile and an unsplit reduction): [rs_gemm_colsum_rows(M, tile), N] partial
+ *   column sums of the finished C, one row per wave row of the grid.  Their sum over rows is sum_m C[m,n] -- the bias
+ *   gradient db = sum_b dZ[b,:] when C is a dZ (nn.Linear's bias backward); rs_colsum_finish_multi adds up the
+ *   partials of several GEMMs (and of rs_head_bwd) in one launch. */
 size_t rs_gemm_workspace_bytes(int M, int N, int splitk);
+int rs_gemm_colsum_rows(int M, int tile);
 int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out /* host pointer */);
 int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
-                float* workspace, size_t workspace_bytes, rs_stream_t stream);
+                float* workspace, size_t workspace_bytes, float* colsum_part, rs_stream_t stream);
+/* out[p][n] = sum_{r < rows[p]} part[p][r*ld[p] + n] for n < n[p], p < count <= 8, in one launch.  The five arrays
+ * are HOST arrays (of device pointers / sizes). */
+int rs_colsum_finish_multi(const float* const* part, const int* rows, const int* n, const int* ld, float* const* out,
+                           int count, rs_stream_t stream);
 
 /* out[n] = sum_m scale[m] * X[m,n] (scale optional): bias gradient of nn.Linear, dgamma/dbeta sums of
  * LayerNorm, and (with scale) the weight gradient of a 1-wide layer. */
@@ -105,6 +114,20 @@ int rs_loss_add_reg(float* loss, const float* partials, const int* seg_end, cons
 int rs_bce_head(const float* z0, const float* z1, const float* z2, const float* labels_f32, const int64_t* labels_i64,
                 int B, float* logit_out, float* prob_out, float* loss_out, float* dz_out, float grad_scale,
                 float* sum_dz_out, const float* hlast, int act_last, float* dzh_out, float* sum_dzh_out,
+                rs_stream_t stream);
+
+/* The same head with the 1-wide last MLP block (an MLPBlock(h_last, 1): model/DeepFM/DeepFM.py:35) fused in:
+ * h = act(X.w + b), logit = z0 + z1 + h (z0, z1 nullable), loss, dz, dzh = dz*act'(h) and their sums in one launch;
+ * and its backward dX = dzh w^T * act'_prev(X) plus part [rs_head_bwd_rows(B), 2K]: partial sums of
+ * [dW = X^T dzh | dbp = column sums of dX], to be added over rows by rs_colsum_finish_multi.
+ * ws: rs_head_workspace_floats(B, K) floats; sem: one int, zero before the first call, left zero. */
+size_t rs_head_workspace_floats(int B, int K);
+int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
+                    const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
+                    float* loss_out, float* dz_out, float* sum_dz_out, float* dzh_out, float* sum_dzh_out, float* ws,
+                    int* sem, rs_stream_t stream);
+int rs_head_bwd_rows(int B);
+int rs_head_bwd(const float* dzh, const float* w, const float* X, int mul_act, int B, int K, float* dX, float* part,
                 rs_stream_t stream);
 
 /* ---- K2: interactions on gathered embeddings emb[B,F,d] -------------------------------------- */
@@ -191,6 +214,7 @@ int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, rs_s
 int rs_opt_prepare(long long* step, float* hyper, rs_stream_t stream);
 int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
                         rs_stream_t stream);
+
 
 /* ---- row-sharded tables: device side of the all-to-all exchange (no reference counterpart: the
  * reference is single-device; semantics are those of Embedding_layer.forward / its backward on the

@@ -30,8 +30,9 @@ _SIGS = {
                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
     # gemm.hip
     "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
-                    I, I, c_f32p, SZ, c_stream],
+                    I, I, c_f32p, SZ, c_f32p, c_stream],
     "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, SZ, c_stream],
+    "rs_colsum_finish_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     # sparse.hip
     "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
@@ -49,6 +50,9 @@ _SIGS = {
                     c_f32p, c_f32p, I, c_f32p, c_f32p, c_stream],
     "rs_rowdot_fwd": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_stream],
     "rs_rowdot_bwd_dx": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_head_fwd_bce": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_f32p, c_f32p, c_i64p, F, c_f32p, c_f32p, c_f32p,
+                        c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream],
+    "rs_head_bwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_act_fwd": [c_f32p, c_f32p, L, I, c_f32p, c_stream],
     "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
     "rs_bn_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, I, F, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
@@ -87,6 +91,9 @@ _PLAIN = {
     "rs_device_cu_count": (I, []),
     "rs_gemm_workspace_bytes": (SZ, [I, I, I]),
     "rs_gemm_plan": (I, [I, I, I, I, C.POINTER(I)]),
+    "rs_gemm_colsum_rows": (I, [I, I]),
+    "rs_head_bwd_rows": (I, [I]),
+    "rs_head_workspace_floats": (SZ, [I, I]),
     "rs_colsum_workspace_bytes": (SZ, [I, I]),
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_sort_max_entries": (I, []),

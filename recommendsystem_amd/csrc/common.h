@@ -53,6 +53,31 @@ __device__ __forceinline__ float rs_block_sum(float v, float* smem /* >= NT/64 f
     return t;
 }
 
+// "Last workgroup finishes the reduction": every workgroup of a launch writes its partial results with
+// rs_st_agent, then calls rs_last_arrival (all threads, uniformly); exactly one workgroup -- the last to
+// arrive at `counter` -- gets true and may read every workgroup's partials with rs_ld_agent.  The partials
+// travel as device-scope (sc1) stores and loads, so no cache-wide write-back or invalidate is needed: a
+// workgroup only waits for its own stores before it signals.  The counter resets itself, so one
+// zero-initialised int serves every launch issued in order on a stream.  s_flag: one int of LDS.
+__device__ __forceinline__ void rs_st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float rs_ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool rs_last_arrival(int* counter, int expected, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(counter, 1);
+        const int last = old == expected - 1;
+        if (last) atomicExch(counter, 0);
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
 // Activation codes shared with the host side.
 enum { RS_ACT_NONE = 0, RS_ACT_RELU = 1, RS_ACT_TANH = 2, RS_ACT_LEAKYRELU = 3, RS_ACT_PRELU = 4 };
 

@@ -91,6 +91,127 @@ __global__ __launch_bounds__(256) void rowdot_bwd_dx_kernel(const float* __restr
     }
 }
 
+
+// ---- fused head: 1-wide last layer + loss head in one launch, and its backward -----------------------
+// Forward (model/DeepFM/DeepFM.py:35,54 + BaseModel.py:145): h[m] = act(X[m,:].w + b), logit = z0 + z1 + h,
+// BCE loss (mean), dz = dL/dlogit * grad_scale, dzh = dz * act'(h).  A workgroup takes 16 rows: each of its
+// four waves forms four row dot products, then 16 lanes do the per-row loss arithmetic.  The per-workgroup
+// sums (loss, sum dz, sum dzh) are added in workgroup order by the last workgroup to arrive.
+constexpr int HEAD_ROWS = 16;
+__global__ __launch_bounds__(256) void head_fwd_bce_kernel(const float* __restrict__ X, int B, int K,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int act, const float* __restrict__ z0,
+                                                           const float* __restrict__ z1, const float* __restrict__ yf,
+                                                           const int64_t* __restrict__ yi, float grad_scale,
+                                                           float* __restrict__ h_out, float* __restrict__ loss_out,
+                                                           float* __restrict__ dz_out, float* __restrict__ sum_dz_out,
+                                                           float* __restrict__ dzh_out, float* __restrict__ sum_dzh_out,
+                                                           float* __restrict__ part /*[grid,4]*/, int* sem) {
+    __shared__ float hrow[HEAD_ROWS];
+    __shared__ int s_flag;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * HEAD_ROWS;
+    const float b0 = bias ? bias[0] : 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 c = *reinterpret_cast<const float4*>(w + k);
+        float4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = r0 + wv * 4 + i;
+            a[i] = m < B ? *reinterpret_cast<const float4*>(X + (long long)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = fmaf(a[i].x, c.x, s[i]); s[i] = fmaf(a[i].y, c.y, s[i]);
+            s[i] = fmaf(a[i].z, c.z, s[i]); s[i] = fmaf(a[i].w, c.w, s[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = rs_wave_sum(s[i]);
+        if (lane == 0) hrow[wv * 4 + i] = rs_act(act, t + b0, 0.f);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int m = r0 + lane;
+        float l = 0.f, dz = 0.f, dzh = 0.f;
+        if (lane < HEAD_ROWS && m < B) {
+            const float h = hrow[lane];
+            // the parts add up in model order (first-order + second-order + deep), as in rs_bce_head
+            float z = h;
+            if (z0 && z1) z = (z0[m] + z1[m]) + h;
+            else if (z0) z = z0[m] + h;
+            const float y = yf ? yf[m] : (float)yi[m];
+            const float p = 1.f / (1.f + expf(-z));
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+            l = -(y * lp + (1.f - y) * l1p);
+            const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (1.f / (float)B) * grad_scale;
+            dz = gp * ((1.f - p) * p);
+            dzh = dz * rs_act_grad(act, h, h, 0.f);
+            if (h_out) h_out[m] = h;
+            if (dz_out) dz_out[m] = dz;
+            if (dzh_out) dzh_out[m] = dzh;
+        }
+        l = rs_wave_sum(l); dz = rs_wave_sum(dz); dzh = rs_wave_sum(dzh);
+        if (lane == 0) {
+            rs_st_agent(part + blockIdx.x * 4 + 0, l);
+            rs_st_agent(part + blockIdx.x * 4 + 1, dz);
+            rs_st_agent(part + blockIdx.x * 4 + 2, dzh);
+        }
+    }
+    if (!rs_last_arrival(sem, gridDim.x, &s_flag)) return;
+    if (wv == 0) {
+        float l = 0.f, dz = 0.f, dzh = 0.f;
+        for (int g = lane; g < (int)gridDim.x; g += 64) {
+            l += rs_ld_agent(part + g * 4 + 0); dz += rs_ld_agent(part + g * 4 + 1); dzh += rs_ld_agent(part + g * 4 + 2);
+        }
+        l = rs_wave_sum(l); dz = rs_wave_sum(dz); dzh = rs_wave_sum(dzh);
+        if (lane == 0) {
+            if (loss_out) loss_out[0] = l * (1.f / (float)B);
+            if (sum_dz_out) sum_dz_out[0] = dz;
+            if (sum_dzh_out) sum_dzh_out[0] = dzh;
+        }
+    }
+}
+
+// Backward of the 1-wide layer:
+//   dX[m,k] = dzh[m] * w[k] * act'_prev(X[m,k])    dW[k] = sum_m dzh[m] X[m,k]    dbp[k] = sum_m dX[m,k]
+// (dbp is the bias gradient of the previous block when its act' is fused, i.e. dX is that block's dZ).
+// A workgroup takes 16 rows, thread t the columns t, t+256, ... (at most 4), and leaves one row of partial
+// column sums [dW | dbp]; the caller adds the partial rows in row order (rs_colsum_finish_multi).
+constexpr int HEAD_KPT = 4;
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dzh, const float* __restrict__ w,
+                                                       const float* __restrict__ X, int mul_act, int B, int K,
+                                                       float* __restrict__ dX, float* __restrict__ part /*[grid,2,K]*/) {
+    __shared__ float sdz[HEAD_ROWS];
+    const int r0 = blockIdx.x * HEAD_ROWS;
+    if (threadIdx.x < HEAD_ROWS) sdz[threadIdx.x] = r0 + threadIdx.x < B ? dzh[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    float* prow = part + (long long)blockIdx.x * 2 * K;
+#pragma unroll
+    for (int u = 0; u < HEAD_KPT; ++u) {
+        const int k = threadIdx.x + u * 256;
+        if (k >= K) break;
+        const float wk = w[k];
+        float x[HEAD_ROWS];
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) x[r] = r0 + r < B ? X[(long long)(r0 + r) * K + k] : 0.f;
+        float aw = 0.f, ab = 0.f;
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) {
+            const float g = sdz[r];
+            float v = g * wk;
+            if (mul_act) v *= rs_act_grad(mul_act, x[r], x[r], 0.f);
+            if (r0 + r < B) dX[(long long)(r0 + r) * K + k] = v;
+            aw = fmaf(g, x[r], aw);
+            ab += v;
+        }
+        prow[k] = aw;
+        prow[K + k] = ab;
+    }
+}
+
 // dst[b] = act(z[b])-style pointwise helpers on vectors -------------------------------------
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, long long n,
                                                       int act, const float* __restrict__ slope) {
@@ -348,6 +469,43 @@ int rs_rowdot_bwd_dx(const float* dz, const float* w, const float* X, int mul_ac
     hipLaunchKernelGGL(rowdot_bwd_dx_kernel, dim3(flat_blocks((long long)M * K)), dim3(256), 0, stream, dz, w, X, mul_act,
                        M, K, dX);
     RS_CHECK_LAUNCH("rs_rowdot_bwd_dx");
+    return RS_OK;
+}
+
+
+// Scratch of the fused head entry points for a batch of M rows and a K-wide input: floats of `ws`.
+size_t rs_head_workspace_floats(int M, int K) {
+    const size_t g = (size_t)rs_cdiv(M, HEAD_ROWS);
+    const size_t a = g * 4, b = g * 2 * (size_t)K;
+    return a > b ? a : b;
+}
+
+// 1-wide last layer + sigmoid/BCE head in one launch (see head_fwd_bce_kernel).  z0, z1: the other logit
+// parts (nullable; z1 needs z0).  sem: one zeroed int (left zero).  ws: rs_head_workspace_floats(B, K).
+int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
+                    const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
+                    float* loss_out, float* dz_out, float* sum_dz_out, float* dzh_out, float* sum_dzh_out, float* ws,
+                    int* sem, hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && K > 0 && X && w && ws && sem, "rs_head_fwd_bce: bad arguments");
+    RS_CHECK_ARG((K & 3) == 0 && ((((uintptr_t)X | (uintptr_t)w) & 15) == 0), "rs_head_fwd_bce: K %% 4 and 16-byte alignment");
+    RS_CHECK_ARG((labels_f32 != nullptr) != (labels_i64 != nullptr), "rs_head_fwd_bce: pass exactly one label array");
+    RS_CHECK_ARG(z0 || !z1, "rs_head_fwd_bce: z1 without z0");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_head_fwd_bce: activation %d not fusable", act);
+    hipLaunchKernelGGL(head_fwd_bce_kernel, dim3(rs_cdiv(B, HEAD_ROWS)), dim3(256), 0, stream, X, B, K, w, bias, act, z0, z1,
+                       labels_f32, labels_i64, grad_scale, h_out, loss_out, dz_out, sum_dz_out, dzh_out, sum_dzh_out, ws, sem);
+    RS_CHECK_LAUNCH("rs_head_fwd_bce");
+    return RS_OK;
+}
+
+// Backward of the 1-wide layer: dX [B,K] and part [rs_head_bwd_rows(B), 2K], the per-16-row partial sums of
+// [dW | dbp] (see head_bwd_kernel); their sums over rows are dW and dbp (rs_colsum_finish_multi).
+int rs_head_bwd_rows(int B) { return rs_cdiv(B, HEAD_ROWS); }
+int rs_head_bwd(const float* dzh, const float* w, const float* X, int mul_act, int B, int K, float* dX, float* part,
+                hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && K > 0 && K <= 256 * HEAD_KPT, "rs_head_bwd: bad sizes (K <= %d)", 256 * HEAD_KPT);
+    RS_CHECK_ARG(dzh && w && X && dX && part, "rs_head_bwd: null argument");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(rs_cdiv(B, HEAD_ROWS)), dim3(256), 0, stream, dzh, w, X, mul_act, B, K, dX, part);
+    RS_CHECK_LAUNCH("rs_head_bwd");
     return RS_OK;
 }
 

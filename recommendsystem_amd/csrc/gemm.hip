@@ -38,6 +38,8 @@ struct GemmArgs {
     int kchunk;             // k range per blockIdx.z (multiple of BK)
     int splitk;
     float* ws;              // [splitk, M, N] partial slabs when splitk > 1
+    float* cs_part;         // [ceil(M / (BM/2)), N] or null: column sums of the finished C per wave row
+                            // (partial bias gradients when C is a dZ), added up by rs_colsum_finish_multi
 };
 
 __device__ __forceinline__ float act_grad_from_h(int act, float h) {
@@ -54,6 +56,47 @@ __device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int
     v = rs_act(g.act, v, 0.f);
     if (g.mulsrc) v *= act_grad_from_h(g.mul_act, g.mulsrc[(long long)m * g.ldm + n]);
     return v;
+}
+
+
+// ---- tile epilogue shared by both kernels ----------------------------------------------------------
+// C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// splitk == 1: epilogue + store; optionally the column sums of the stored values over the wave's BM/2 rows.
+// splitk  > 1: raw slab store (splitk_reduce_kernel adds the slabs and applies the epilogue).
+template <int BM, int BN>
+__device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0, int wm0,
+                                            int wn0, int li, int lh) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const bool partial = g.splitk > 1;
+    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = partial ? g.N : g.ldc;
+    float cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cs[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (!partial) v = epilogue(g, v, m, n);
+                    out[(long long)m * ldo + n] = v;
+                    cs[j] += v;
+                }
+            }
+        }
+    if (partial || !g.cs_part) return;
+    const int prow = (m0 + wm0) / (BM / 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float t = cs[j] + __shfl_xor(cs[j], 32, 64);
+        const int n = n0 + wn0 + j * 32 + li;
+        if (lh == 0 && n < g.N && m0 + wm0 < g.M) g.cs_part[(long long)prow * g.N + n] = t;
+    }
 }
 
 // ---- tile staging -----------------------------------------------------------------------------
@@ -172,25 +215,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const bool partial = g.splitk > 1;
-    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
-    const int ldo = partial ? g.N : g.ldc;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < g.M && n < g.N) {
-                    float v = acc[i][j][r];
-                    if (!partial) v = epilogue(g, v, m, n);
-                    out[(long long)m * ldo + n] = v;
-                }
-            }
-        }
+    finish_tile<BM, BN>(g, acc, m0, n0, wm0, wn0, li, lh);
 }
 
 // =================================================================================================
@@ -425,24 +450,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the two trailing (zero) tiles
 
-    const bool partial = g.splitk > 1;
-    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
-    const int ldo = partial ? g.N : g.ldc;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < g.M && n < g.N) {
-                    float v = acc[i][j][r];
-                    if (!partial) v = epilogue(g, v, m, n);
-                    out[(long long)m * ldo + n] = v;
-                }
-            }
-        }
+    finish_tile<BM, BN>(g, acc, m0, n0, wm0, wn0, li, lh);
 }
 
 // Sum the split-K slabs in slab order and apply the epilogue.
@@ -599,6 +607,41 @@ __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restr
     if (r == 0 && n < N) out[n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// Several column-sum reductions in one launch: problem p adds the `rows[p]` partial rows part[p][r*ld[p] + n]
+// (n < n[p]) in row order into out[p][n].  16 columns per workgroup: thread (c = tid % 16, r = tid / 16) adds
+// rows r, r+16, ..., then the 16 row groups of a column meet in LDS.
+constexpr int CF_MAX = 8;
+struct ColsumFinishArgs {
+    const float* part[CF_MAX]; float* out[CF_MAX];
+    int rows[CF_MAX], n[CF_MAX], ld[CF_MAX], first_block[CF_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumFinishArgs a) {
+    __shared__ float red[16][17];
+    int p = 0;
+    while (p + 1 < a.count && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int n = ((int)blockIdx.x - a.first_block[p]) * 16 + c;
+    const float* part = a.part[p];
+    const int rows = a.rows[p], ld = a.ld[p];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < a.n[p]) {
+        for (int g = r; g < rows; g += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (g + 16 * u < rows) s[u] += part[(long long)(g + 16 * u) * ld + n];
+        }
+    }
+    red[r][c] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (r == 0 && n < a.n[p]) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        a.out[p][n] = t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -627,13 +670,19 @@ int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out) {
     return tile;
 }
 
+// Rows of the partial column sums a GEMM with tile code `tile` leaves for an M-row output (one per wave row).
+int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile == 1) ? 64 : 32); }
+
 // C = epi(op(A) op(B)); see the header of this file for operand conventions.
-// tile < 0 and splitk <= 0 let the library choose.  workspace is needed only when the resolved
-// split count is > 1 (query the size with rs_gemm_workspace_bytes using the same splitk, or pass
-// a buffer sized for splitk = 16).
+// tile < 0 and splitk <= 0 let the library choose.  workspace is needed when the resolved split count is > 1
+// (rs_gemm_workspace_bytes with the same splitk, or sized for splitk = 16).
+// colsum_part (optional, [rs_gemm_colsum_rows(M, tile), N], needs an explicit tile and a resolved splitk of 1):
+// receives per-wave-row column sums of the finished C; their sum over rows (rs_colsum_finish_multi) is
+// sum_m C[m, n] -- the bias gradient when C is a dZ.
 int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
-                int tile, int splitk, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+                int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part,
+                hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "rs_gemm_f32: negative size");
     if (M == 0 || N == 0) return RS_OK;
     RS_CHECK_ARG(A && B && C, "rs_gemm_f32: null operand");
@@ -641,6 +690,7 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
     RS_CHECK_ARG(lda >= (a_mc ? M : K) && ldb >= (b_nc ? N : K) && ldc >= N, "rs_gemm_f32: bad leading dims");
     RS_CHECK_ARG(!mulsrc || ldm >= N, "rs_gemm_f32: bad ldm");
     RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_gemm_f32: activation %d not fusable", act);
+    RS_CHECK_ARG(!colsum_part || tile >= 0, "rs_gemm_f32: colsum_part needs an explicit tile (its row count depends on it)");
     int cus = 256;
     if (tile < 0 || splitk <= 0) {
         int sk = 1;
@@ -655,14 +705,40 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
     if (splitk > 1)
         RS_CHECK_ARG(workspace && workspace_bytes >= rs_gemm_workspace_bytes(M, N, splitk),
                      "rs_gemm_f32: workspace too small for splitk=%d (%zu bytes given)", splitk, workspace_bytes);
-    GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace};
+    RS_CHECK_ARG(!colsum_part || splitk == 1, "rs_gemm_f32: colsum_part needs an unsplit reduction (splitk resolved to %d)",
+                 splitk);
+    GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part};
     g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
     const bool va = aligned16(A) && lda % 4 == 0 && (a_mc ? M % 4 == 0 : K % 4 == 0);
     const bool vb = aligned16(B) && ldb % 4 == 0 && (b_nc ? N % 4 == 0 : K % 4 == 0);
+    RS_CHECK_ARG(!colsum_part || (tile != 0 && tile != 1) || (va && vb),
+                 "rs_gemm_f32: colsum_part with 128-row tiles needs 16-byte aligned operands");
     if (!a_mc && !b_nc) return dispatch<false, false>(g, va, vb, tile, stream);
     if (!a_mc && b_nc) return dispatch<false, true>(g, va, vb, tile, stream);
     return dispatch<true, true>(g, va, vb, tile, stream);
+}
+
+// out[p][n] = sum_r part[p][r*ld[p] + n], r < rows[p], n < n[p], for p < count (<= 8) problems in one launch.
+// All five arrays are HOST arrays of length count (the pointers in them are device pointers).
+int rs_colsum_finish_multi(const float* const* part, const int* rows, const int* n, const int* ld, float* const* out,
+                           int count, hipStream_t stream) {
+    RS_CHECK_ARG(count >= 0 && count <= CF_MAX, "rs_colsum_finish_multi: at most %d problems", CF_MAX);
+    if (count == 0) return RS_OK;
+    RS_CHECK_ARG(part && rows && n && ld && out, "rs_colsum_finish_multi: null argument");
+    ColsumFinishArgs a;
+    int blocks = 0;
+    for (int p = 0; p < count; ++p) {
+        RS_CHECK_ARG(part[p] && out[p] && rows[p] >= 0 && n[p] > 0 && ld[p] >= n[p], "rs_colsum_finish_multi: bad problem %d", p);
+        a.part[p] = part[p]; a.out[p] = out[p]; a.rows[p] = rows[p]; a.n[p] = n[p]; a.ld[p] = ld[p];
+        a.first_block[p] = blocks;
+        blocks += rs_cdiv(n[p], 16);
+    }
+    a.first_block[count] = blocks;
+    a.count = count;
+    hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    RS_CHECK_LAUNCH("rs_colsum_finish_multi");
+    return RS_OK;
 }
 
 size_t rs_colsum_workspace_bytes(int M, int N) { return (size_t)rs_cdiv(M, CS_ROWS) * N * sizeof(float); }

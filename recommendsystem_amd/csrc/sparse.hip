@@ -90,35 +90,60 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
     for (int j = n + t; j < CAPB; j += SORT_THREADS) buf[j] = ~0ull;   // sentinels sort last
     __syncthreads();
 
-    unsigned long long it[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
-
     int nbits = 1;
     {
         unsigned long long vmax = (unsigned long long)(a.vocab[f] - 1);
         while ((vmax >> nbits) != 0 && nbits < 32) ++nbits;
     }
-    for (int bit = 0; bit < nbits; ++bit) {
-        const int sh = 32 + bit;
-        int zl = 0;
+    // ---- stable LSD radix sort, DB key bits per pass ----------------------------------------------
+    // Items are taken striped (item j of thread t is element j*1024 + t), so the 64 lanes of a wave hold a
+    // contiguous run of elements: one ballot per digit bit gives, for every digit value, the run's count
+    // (lanes 0..NB-1 each build the mask of "their" value) and every lane's rank inside the run; an exclusive
+    // scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that NB * runs = 1024.
+    {
+        constexpr int DB = ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2);
+        constexpr int NB = 1 << DB;
+        constexpr int G = 16 * ITEMS;                 // runs of 64 elements
+        static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
+        int* cnt = scratch + 32;                      // [NB][G]
+        const int lane = t & 63, w = t >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int bit = 0; bit < nbits; bit += DB) {
+            const int sh = 32 + bit;
+            unsigned long long x[ITEMS], mk[ITEMS];
+            int dg[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) zl += 1 - (int)((it[j] >> sh) & 1ull);
-        int total_zeros;
-        const int ex = block_excl_scan(zl, scratch, &total_zeros);
-        int z = ex, o = total_zeros + (t * ITEMS - ex);
+            for (int j = 0; j < ITEMS; ++j) {
+                x[j] = buf[j * SORT_THREADS + t];
+                const int dgt = (int)((x[j] >> sh) & (unsigned long long)(NB - 1));
+                unsigned long long own = ~0ull, mine = ~0ull;      // mask of my digit / of digit value `lane`
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int b1 = (int)((it[j] >> sh) & 1ull);
-            const int rank = b1 ? o : z;
-            o += b1; z += 1 - b1;
-            buf[rank] = it[j];
+                for (int k = 0; k < DB; ++k) {
+                    const unsigned long long mb = __ballot((dgt >> k) & 1);
+                    own &= ((dgt >> k) & 1) ? mb : ~mb;
+                    mine &= ((lane >> k) & 1) ? mb : ~mb;
+                }
+                if (lane < NB) cnt[lane * G + j * 16 + w] = __popcll(mine);
+                dg[j] = dgt;
+                mk[j] = own;
+            }
+            __syncthreads();
+            const int v = cnt[t];
+            int tot_unused;
+            const int ex = block_excl_scan(v, scratch, &tot_unused);
+            cnt[t] = ex;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int rank = cnt[dg[j] * G + j * 16 + w] + __popcll(mk[j] & lt);
+                buf[rank] = x[j];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
-        __syncthreads();
     }
+    unsigned long long it[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
 
     // ---- segmentation: heads of runs of equal keys, chunk heads every L sorted positions ----
     int flags[ITEMS];
@@ -471,6 +496,7 @@ __global__ __launch_bounds__(256) void clip_prepare_kernel(const float* __restri
     }
 }
 
+
 int lanes_for(int d, int* VEC, int* C) {
     if (d % 4 == 0 && d / 4 <= 64) { *VEC = 4; *C = d / 4; return 0; }
     if (d <= 64) { *VEC = 1; *C = d; return 0; }
@@ -518,7 +544,7 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     int items = 1;
     while (items * SORT_THREADS < max_entries) items <<= 1;
     if (items < 4) items = 4;
-    const size_t smem = (size_t)SORT_THREADS * items * 8 + 32 * sizeof(int);
+    const size_t smem = (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int);   // items, scan scratch, one count per thread
 #define RS_SORT_LAUNCH(IT)                                                                          \
     do {                                                                                            \
         static bool attr = false;                                                                   \
@@ -678,6 +704,7 @@ int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* sca
     RS_CHECK_LAUNCH("rs_clip_and_prepare");
     return RS_OK;
 }
+
 
 // *step += 1 and refresh the Adam bias-correction scalars in hyper[5], hyper[6].
 int rs_opt_prepare(long long* step, float* hyper, hipStream_t stream) {

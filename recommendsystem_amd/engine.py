@@ -117,7 +117,8 @@ class FusedTrainer:
 
         last = self.blocks[-1] if self.blocks else None
         self._head_fast = bool(last is not None and last.fc.out_features == 1 and not last.normalization
-                               and last._act in _FUSABLE and last.fc.in_features % 4 == 0)
+                               and last._act in _FUSABLE and last.fc.in_features % 4 == 0
+                               and last.fc.in_features <= 1024)
         self._flatten_dense()
         self._alloc_state()
         self._plans: Dict[int, ops.SparsePlan] = {}
@@ -209,8 +210,9 @@ class FusedTrainer:
         return self._plans[B]
 
     # ------------------------------------------------------------------------------------------
-    def forward_parts(self, idx: torch.Tensor):
-        """Forward pass; returns (logit parts, saved context)."""
+    def forward_parts(self, idx: torch.Tensor, defer_head: bool = False):
+        """Forward pass; returns (logit parts, saved context).  defer_head: leave a 1-wide last block to the
+        caller (the training step fuses it with the loss head); then ctx["head_in"] is its input."""
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
@@ -226,6 +228,11 @@ class FusedTrainer:
             cs = []
             for bi, b in enumerate(self.blocks):
                 if bi == len(self.blocks) - 1 and self._head_fast:
+                    if defer_head:
+                        cs.append(("head", h, None))
+                        ctx["head_in"] = h
+                        h = None
+                        break
                     # 1-wide head: one wave per row instead of a 64-wide GEMM tile
                     hh = ops.rowdot_fwd(h, b.fc.weight.data.view(-1), b.fc.bias.data, b._act)
                     cs.append(("head", h, hh))
@@ -243,7 +250,8 @@ class FusedTrainer:
                                         beta, slope, self.model.training, rm, rv, eps)
                 cs.append(c)
             ctx["mlp"] = cs
-            parts.append(h.view(B))
+            if h is not None:
+                parts.append(h.view(B))
         return parts, ctx
 
     # ---- embedding hooks (overridden by the row-sharded multi-GPU trainer) -----------------------
@@ -308,14 +316,19 @@ class FusedTrainer:
         if fork_sort:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
-        parts, ctx = self.forward_parts(idx)
         head_fast = bool(self.blocks) and self._head_fast
+        parts, ctx = self.forward_parts(idx, defer_head=head_fast)
         lastb = self.blocks[-1] if self.blocks else None
-        head = ops.bce_head(parts, labels, want_dz=True, grad_scale=self._grad_scale(),
-                            sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None,
-                            hlast=parts[-1] if head_fast else None, act_last=lastb._act if head_fast else 0,
-                            want_dzh=head_fast,
-                            sum_dzh_out=self.gviews[id(lastb.fc.bias)] if head_fast else None)
+        if head_fast:
+            # the 1-wide last block, the loss and dL/dlogit in one launch
+            head = ops.head_fwd_bce(ctx["head_in"], lastb.fc.weight.data.view(-1), lastb.fc.bias.data, lastb._act, parts,
+                                    labels, grad_scale=self._grad_scale(),
+                                    sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None,
+                                    sum_dzh_out=self.gviews[id(lastb.fc.bias)])
+            parts = parts + [head["h"]]
+        else:
+            head = ops.bce_head(parts, labels, want_dz=True, grad_scale=self._grad_scale(),
+                                sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None)
         loss, dz = head["loss"], head["dz"]
         keep += [parts, ctx, head]
 
@@ -336,14 +349,17 @@ class FusedTrainer:
                 else:
                     fn()
 
+            db_done = False              # the bias gradient of the block about to be visited is already on its way
+            csp = ops.ColsumParts(ops.default_workspace(self.device))    # partial column sums -> one finishing launch
             if head_fast:
                 _, xin, _ = cs[top]
-                dzh = head["dzh"]
                 prev = self.blocks[top - 1] if top > 0 else None
                 fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
-                wgrad(lambda: ops.colsum(xin, out=self.gviews[id(lastb.fc.weight)].view(-1), scale=dzh))   # dz^T X
-                dh = ops.rowdot_bwd_dx(dzh, lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0)
-                dz_ready = fuse_prev
+                # dX, dW of the head and (when the previous act' is fused) the previous block's bias gradient
+                dh = ops.head_bwd(head["dzh"], lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0, csp,
+                                  dW_out=self.gviews[id(lastb.fc.weight)].view(-1),
+                                  dbp_out=self.gviews[id(prev.fc.bias)] if fuse_prev else None)
+                dz_ready = db_done = fuse_prev
                 top -= 1
             for i in range(top, -1, -1):
                 b, c = self.blocks[i], cs[i]
@@ -353,10 +369,18 @@ class FusedTrainer:
                     dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
                     keep.append(dzl)
                     gW, gb = self.gviews[id(b.fc.weight)], self.gviews[id(b.fc.bias)]
-                    wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW),
-                                                              ops.colsum(dzl, out=gb)))
+                    if db_done:
+                        wgrad(lambda dzl=dzl, c=c, gW=gW: ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW))
+                    else:
+                        wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW),
+                                                                  ops.colsum(dzl, out=gb)))
+                    # dX of this block = dZ of the previous one when its act' rides in the epilogue; its column
+                    # sums (the previous block's bias gradient) then come out of the same launch
+                    if fuse_prev:
+                        csp.expect(self.gviews[id(prev.fc.bias)])
                     dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
-                                  mul_act=prev._act if fuse_prev else 0)
+                                  mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None)
+                    db_done = fuse_prev
                 else:
                     r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
                                          dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
@@ -368,8 +392,10 @@ class FusedTrainer:
                         self.gviews[id(b.activation_func.weight)].copy_(r["dslope"])
                     dh = r["dx"]
                     keep.append(r)
+                    db_done = False
                 dz_ready = fuse_prev
                 keep.append(dh)
+            csp.finish()
             gout = dh.view(B * self.F, self.d)
 
         if fork_sort:

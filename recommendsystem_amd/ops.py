@@ -104,10 +104,12 @@ class Workspace:
         self.device = torch.device(device)
         self._bufs = {}
 
-    def get(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+    def get(self, name: str, numel: int, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+        """zero=True: the buffer starts zeroed and its users leave it zeroed (arrival counters)."""
         b = self._bufs.get(name)
         if b is None or b.numel() < numel or b.dtype != dtype:
-            b = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            mk = torch.zeros if zero else torch.empty
+            b = mk(max(int(numel), 1), dtype=dtype, device=self.device)
             self._bufs[name] = b
         return b
 
@@ -150,11 +152,14 @@ OPT_CODES = {"SGD": 0, "Adam": 1, "AdamW": 2, "Adagrad": 3}
 # GEMM
 # ---------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
-         mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None) -> torch.Tensor:
+         mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None) -> torch.Tensor:
     """C = epi(op(A) op(B)) in fp32 on the matrix cores.
 
     a_mc=False: a is [M, K];  a_mc=True: a is [K, M] (used as its transpose).
     b_nc=False: b is [N, K] (nn.Linear weight);  b_nc=True: b is [K, N].
+    colsum_part: a ColsumParts collector; the GEMM leaves per-wave-row column sums of C in a scratch buffer and
+    registers (buffer, rows, N, destination) with it -- ColsumParts.finish() adds them up in one launch for
+    every registered GEMM (the bias gradients of the dZ's the backward chain produces).
     """
     _chk(a, torch.float32, "a")
     _chk(b, torch.float32, "b")
@@ -181,14 +186,70 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
             tile = t
         if splitk <= 0:
             splitk = sk.value
+    ws = ws or default_workspace(a.device)
     wbuf, wbytes = None, 0
     if splitk > 1:
-        ws = ws or default_workspace(a.device)
         wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
         wbuf = ws.get("gemm_splitk", wbytes // 4)
+    part = None
+    if colsum_part is not None and splitk == 1:
+        aligned = all(t.data_ptr() % 16 == 0 and t.shape[1] % 4 == 0 for t in (a, b))
+        if tile in (0, 1) and not aligned:
+            tile = 3
+        rows = h.rs_gemm_colsum_rows(M, tile)
+        part = colsum_part.buffer(rows * N)
+        colsum_part.add(part, rows, N, N)
     call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), a.shape[1], ptr(b), b.shape[1], ptr(out), N,
-         ptr(bias), int(act), ptr(mulsrc), N, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, stream())
+         ptr(bias), int(act), ptr(mulsrc), N, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
+         stream())
+    if colsum_part is not None and part is None:
+        colsum(out, out=colsum_part.take_destination(), ws=ws)        # split reduction: separate column-sum launch
     return out
+
+
+class ColsumParts:
+    """Collects partial column sums left behind by several producers and adds them up in one launch.
+
+    Usage: p = ColsumParts(ws); p.expect(dest); ops.gemm(..., colsum_part=p); ...; p.finish()."""
+
+    def __init__(self, ws: "Workspace"):
+        self.ws = ws
+        self._items = []            # (part tensor, rows, n, ld, dest)
+        self._dest = None
+        self._k = 0
+
+    def expect(self, dest: torch.Tensor):
+        """Destination [N] of the next producer's column sums."""
+        self._dest = dest
+        return self
+
+    def take_destination(self):
+        d, self._dest = self._dest, None
+        if d is None:
+            raise RSError("ColsumParts: expect(dest) must precede the producer")
+        return d
+
+    def buffer(self, numel: int) -> torch.Tensor:
+        self._k += 1
+        return self.ws.get(f"colsum_part_{self._k}", numel)
+
+    def add(self, part: torch.Tensor, rows: int, n: int, ld: int, dest: Optional[torch.Tensor] = None, offset: int = 0):
+        dest = dest if dest is not None else self.take_destination()
+        _chk(dest, torch.float32, "colsum destination", (n,))
+        self._items.append((part, int(rows), int(n), int(ld), dest, int(offset)))
+
+    def finish(self):
+        import ctypes as C
+        items, self._items, self._k = self._items, [], 0
+        for i in range(0, len(items), 8):
+            grp = items[i:i + 8]
+            k = len(grp)
+            P = (C.c_void_p * k)(*[g[0].data_ptr() + 4 * g[5] for g in grp])
+            O = (C.c_void_p * k)(*[g[4].data_ptr() for g in grp])
+            R = (C.c_int * k)(*[g[1] for g in grp])
+            Nn = (C.c_int * k)(*[g[2] for g in grp])
+            L = (C.c_int * k)(*[g[3] for g in grp])
+            call("rs_colsum_finish_multi", P, R, Nn, L, O, k, stream())
 
 
 def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None, scale=None) -> torch.Tensor:
@@ -246,6 +307,57 @@ def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, wan
          ptr(hlast.reshape(-1) if hlast is not None else None), int(act_last), ptr(out.get("dzh")), ptr(sum_dzh_out),
          stream())
     return out
+
+
+def head_fwd_bce(x: torch.Tensor, w: torch.Tensor, bias, act: int, parts, labels: torch.Tensor, grad_scale=1.0,
+                 sum_dz_out=None, sum_dzh_out=None, ws: Optional[Workspace] = None):
+    """1-wide last layer + loss head in one launch: h = act(x.w + b); logit = sum(parts) + h.
+    Returns dict(loss [1], dz [B], dzh [B], h [B])."""
+    _chk(x, torch.float32, "x")
+    B, K = x.shape
+    _chk(w, torch.float32, "w")
+    if w.numel() != K:
+        raise RSError("head_fwd_bce: weight length differs from the input width")
+    parts = [p.reshape(-1) for p in parts if p is not None]
+    if len(parts) > 2:
+        raise RSError("head_fwd_bce: at most two other logit parts")
+    for p in parts:
+        _chk(p, torch.float32, "logit part", (B,))
+    parts = parts + [None] * (2 - len(parts))
+    lf = li = None
+    if labels.dtype == torch.float32:
+        lf = labels
+    elif labels.dtype == torch.int64:
+        li = labels
+    else:
+        raise RSError(f"head_fwd_bce: labels must be float32 or int64, got {labels.dtype}")
+    _chk(labels, labels.dtype, "labels", (B,))
+    dev = x.device
+    ws = ws or default_workspace(dev)
+    wbuf = ws.get("head_ws", _lib.lib().rs_head_workspace_floats(B, K))
+    sem = ws.get("head_sem", 1, dtype=torch.int32, zero=True)
+    out = {k: torch.empty(B, dtype=torch.float32, device=dev) for k in ("dz", "dzh", "h")}
+    out["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
+    call("rs_head_fwd_bce", ptr(x), B, K, ptr(w), ptr(bias), int(act), ptr(parts[0]), ptr(parts[1]), ptr(lf), ptr(li),
+         float(grad_scale), ptr(out["h"]), ptr(out["loss"]), ptr(out["dz"]), ptr(sum_dz_out), ptr(out["dzh"]),
+         ptr(sum_dzh_out), ptr(wbuf), ptr(sem), stream())
+    return out
+
+
+def head_bwd(dzh: torch.Tensor, w: torch.Tensor, x: torch.Tensor, mul_act: int, parts: "ColsumParts",
+             dW_out: torch.Tensor, dbp_out=None) -> torch.Tensor:
+    """Backward of the 1-wide layer; returns dx and registers the partial sums of dW_out [K] (and of dbp_out [K] =
+    column sums of dx, the previous block's bias gradient when its act' is fused through mul_act) with `parts`."""
+    M, K = x.shape
+    _chk(dzh, torch.float32, "dzh", (M,))
+    rows = _lib.lib().rs_head_bwd_rows(M)
+    part = parts.buffer(rows * 2 * K)
+    dx = torch.empty_like(x)
+    call("rs_head_bwd", ptr(dzh), ptr(w), ptr(x), int(mul_act), M, K, ptr(dx), ptr(part), stream())
+    parts.add(part, rows, K, 2 * K, dest=dW_out, offset=0)
+    if dbp_out is not None:
+        parts.add(part, rows, K, 2 * K, dest=dbp_out, offset=K)
+    return dx
 
 
 def rowdot_fwd(x: torch.Tensor, w: torch.Tensor, bias, act: int) -> torch.Tensor:

@@ -52,7 +52,7 @@ def test_argument_errors_do_not_need_a_gpu():
     rc = h.rs_gather_fwd(None, None, None, None, None, 4, 2, 16, None, None)
     assert rc == -1 and b"null" in h.rs_last_error_string()
     rc = h.rs_gemm_f32(1, 0, 8, 8, 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8,
-                       None, 0, None, 0, 0, -1, 0, None, 0, None)
+                       None, 0, None, 0, 0, -1, 0, None, 0, None, None)
     assert rc == -1 and b"layout" in h.rs_last_error_string()
 
 

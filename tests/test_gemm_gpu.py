@@ -123,3 +123,36 @@ def test_mfma_fragment_layout_with_asymmetric_data():
     assert torch.equal(got.cpu(), Bm)
     got = ops.gemm(I.cuda(), Bm.cuda(), a_mc=True, b_nc=True)
     assert torch.equal(got.cpu(), Bm)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 512), (4096, 512, 256), (300, 200, 64), (64, 64, 32), (130, 70, 40),
+                                   (1000, 37, 128), (33, 5, 7)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_colsum_byproduct(M, N, K, tile):
+    """Column sums of the stored C (after the epilogue) as a by-product, e.g. db of the dZ a dX-GEMM produces;
+    several producers are finished by one launch."""
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = torch.randn(K, N, generator=g).cuda()
+    H = torch.randn(M, N, generator=g).cuda()
+    cs = torch.full((N,), 7.0, device="cuda")
+    cs_b = torch.full((N,), 7.0, device="cuda")
+    parts = ops.ColsumParts(ops.Workspace("cuda:0"))
+    for _ in range(2):
+        C = ops.gemm(A, W, b_nc=True, mulsrc=H, mul_act=1, tile=tile, splitk=1, colsum_part=parts.expect(cs))
+        C2 = ops.gemm(A, W, b_nc=True, tile=tile, splitk=1, colsum_part=parts.expect(cs_b))
+        parts.finish()
+        for c, s_ in ((C, cs), (C2, cs_b)):
+            want = c.double().sum(0)
+            bound = c.double().abs().sum(0)
+            assert ((s_.double() - want).abs() <= 1e-6 * bound + 1e-30).all()
+    plain = ops.gemm(A, W, b_nc=True, mulsrc=H, mul_act=1, tile=tile, splitk=1)
+    assert torch.equal(plain, C)
+    # split reductions fall back to a separate column-sum launch
+    if K >= 64:
+        cs2 = torch.zeros(N, device="cuda")
+        ops.gemm(A, W, b_nc=True, tile=tile, splitk=2, colsum_part=parts.expect(cs2))
+        parts.finish()
+        ref = ops.gemm(A, W, b_nc=True, tile=tile, splitk=2).double()
+        assert ((cs2.double() - ref.sum(0)).abs() <= 1e-6 * ref.abs().sum(0) + 1e-30).all()
