@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--distinct-batches", type=int, default=8)
+    p.add_argument("--event-pass", type=int, default=1,
+                   help="after the timed region, run the same K steps eagerly with HIP events around every launch "
+                        "(per-kernel durations for the roofline figures)")
     p.add_argument("--rehearse-on-one-gpu", type=int, default=0,
                    help="N>1 only: all ranks share cuda:0 and exchange through gloo with host staging (functional "
                         "rehearsal of the multi-GPU path on a one-GPU box; the numbers mean nothing)")
@@ -151,10 +154,6 @@ def main():
     barrier()
     torch.cuda.synchronize()
 
-    timer = None
-    if not args.graph:
-        timer = KernelTimer()
-        timer.__enter__()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
@@ -162,19 +161,28 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if timer is not None:
-        timer.__exit__()
-    measured_in = "timed region"
-    if timer is None:
-        # graph replay cannot carry events: time the same launches in an eager pass of the same K steps
-        eager = eng
-        was_graph = eager.use_graph
-        eager.use_graph = False
-        with KernelTimer() as timer:
+
+    # Per-launch durations: the same K steps issued eagerly with a HIP event pair around every launch, on the
+    # launch stream.  A spin kernel in front of every step keeps the GPU busy while the host enqueues the step, so
+    # that each event pair brackets only its kernel (no host launch latency between the two timestamps).
+    timer = KernelTimer(names=None)
+    measured_in = "separate eager pass of the same K steps, HIP events around every launch"
+    if args.event_pass:
+        was_graph = eng.use_graph
+        eng.use_graph = False
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize()
+        cycles_per_ms = 1000000 / max(e0.elapsed_time(e1), 1e-3)
+        for i in range(2):
+            eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
+        torch.cuda.synchronize()
+        timer.calibrate()
+        with timer:
             for i in range(args.steps):
-                eager.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
-        eager.use_graph = was_graph
-        measured_in = "separate eager pass of the same K steps (graph replay cannot carry events)"
+                torch.cuda._sleep(int(6.0 * cycles_per_ms))
+                eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
+                torch.cuda.synchronize()
+        eng.use_graph = was_graph
     summ = timer.summary()
     final_loss = float(loss.item())
     if world > 1:
@@ -191,6 +199,7 @@ def main():
     gemm_flop = gemm_us = 0.0
     gather = None
     per_step = {}
+    by_layout = {}
     for (name, shape), a in sorted(summ.items(), key=lambda kv: -kv[1]["total_us"]):
         per_step[name] = per_step.get(name, 0.0) + a["total_us"] / args.steps
         ent = {"entry": name, "shape": shape, "launches": a["n"], "avg_us": round(a["avg_us"], 2)}
@@ -199,11 +208,19 @@ def main():
             ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
             gemm_flop += a["work"] * a["n"]
             gemm_us += a["total_us"]
+            # the three kernel instantiations a profiler lists: NT = forward <false,false>, NN = dX <false,true>,
+            # TN = dW <true,true> (+ its split-K reduce launch)
+            lay = by_layout.setdefault(shape.split()[0], {"launches": 0, "total_us": 0.0})
+            lay["launches"] += a["n"]
+            lay["total_us"] += a["total_us"]
         elif a["unit"] == "byte":
             ent["gbs"] = round(a["work"] / a["avg_us"] / 1e3, 1)
             ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e3 / HBM_PEAK_GBS, 4)
             gather = (a, ent)
         kernels.append(ent)
+    for lay in by_layout.values():
+        lay["avg_us"] = round(lay["total_us"] / max(lay["launches"], 1), 2)
+        lay["total_us"] = round(lay["total_us"], 1)
     traffic = None
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tp):
@@ -211,14 +228,17 @@ def main():
             traffic = json.load(open(tp)).get("dominant_kernel_hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    roofline = None
     if gemm_us > 0:
         ach = gemm_flop / gemm_us / 1e6
         roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all MLP GEMM launches of a step",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_flop_per_step": gemm_flop / args.steps, "us_per_step": round(gemm_us / args.steps, 1),
-                    "measured_in": measured_in}
-    else:
+                    "launches_per_step": sum(l["launches"] for l in by_layout.values()) / args.steps,
+                    "avg_us_by_layout": by_layout, "measured_in": measured_in,
+                    "event_pair_overhead_us_subtracted": round(timer.overhead_us, 2)}
+    elif gather is not None:
         a, ent = gather
         roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ent["frac_of_peak"], "traffic": traffic, "measured_in": measured_in}

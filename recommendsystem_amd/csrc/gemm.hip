@@ -59,6 +59,24 @@ __device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int
 }
 
 
+// Output-tile coordinates of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (each with its
+// own L2), so the linear block id is first remapped so that the blocks sharing an XCD take one contiguous chunk
+// of the tile sequence (bijective for any grid size), and the sequence itself walks the grid in groups of 8
+// tile rows: the blocks resident on an XCD at one time then share A row panels and B column panels in its L2.
+__device__ __forceinline__ void tile_coords(int& tm, int& tn) {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+    const int orig = blockIdx.y * gx + blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * gx;
+    const int group = t / per_group, first_m = group * GROUP_M;
+    const int gsz = min(gy - first_m, GROUP_M);
+    const int rem = t - group * per_group;
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+}
+
 // ---- tile epilogue shared by both kernels ----------------------------------------------------------
 // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // splitk == 1: epilogue + store; optionally the column sums of the stored values over the wave's BM/2 rows.
@@ -164,7 +182,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    tile_coords(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -336,7 +356,9 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    tile_coords(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + 31) / 32;

@@ -40,10 +40,27 @@ KEYERS = {"rs_gemm_f32": _gemm_key, "rs_gather_lr_fm_fwd": _gather_key}
 
 
 class KernelTimer:
-    def __init__(self, names=("rs_gemm_f32", "rs_gather_lr_fm_fwd", "rs_sparse_bwd_sort", "rs_sparse_bwd_reduce",
-                              "rs_sparse_update", "rs_dense_update", "rs_colsum_f32", "rs_bce_head")):
-        self.names = set(names)
+    def __init__(self, names=None):
+        """names: entry points to time (None: every entry point that takes a stream)."""
+        self.names = set(names) if names is not None else set(_lib._SIGS)
         self.records = []          # (key, work, unit, start_event, end_event)
+        self.overhead_us = 0.0     # duration an event pair reports with nothing between the two records
+
+    def calibrate(self, pairs: int = 64):
+        """Median duration of an empty event pair on the current stream (subtracted from every record)."""
+        ev = []
+        torch.cuda.synchronize()
+        torch.cuda._sleep(2000000)                 # let the host run ahead of the GPU, as in the measured pass
+        for _ in range(pairs):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            e.record()
+            ev.append((s, e))
+        torch.cuda.synchronize()
+        d = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
+        self.overhead_us = d[len(d) // 2]
+        return self.overhead_us
 
     def __enter__(self):
         self._orig = _lib.call
@@ -80,7 +97,7 @@ class KernelTimer:
         for key, work, unit, s, e in self.records:
             a = agg[key]
             a["n"] += 1
-            a["total_us"] += s.elapsed_time(e) * 1e3
+            a["total_us"] += max(s.elapsed_time(e) * 1e3 - self.overhead_us, 0.0)
             a["work"] = work
             a["unit"] = unit
         for a in agg.values():
