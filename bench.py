@@ -43,6 +43,12 @@ def parse():
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--distinct-batches", type=int, default=8)
+    p.add_argument("--force-dist", type=int, default=0,
+                   help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
+                        "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
+    p.add_argument("--dist-graph", type=int, default=0,
+                   help="N>1: replay the kernels between the collectives as HIP-graph segments (default: eager; measured "
+                        "slower than eager on one rank, unmeasured on eight)")
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
@@ -118,9 +124,11 @@ def main():
     rehearse = bool(args.rehearse_on_one_gpu) and world > 1
     device = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or bool(args.force_dist)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -131,9 +139,9 @@ def main():
 
     model, rec, hidden = build(args, device)
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
-    if world > 1:
+    if use_dist:
         from recommendsystem_amd.dist import DistributedTrainer
-        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.graph), stage_cpu=rehearse)
+        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.dist_graph), stage_cpu=rehearse)
     else:
         eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
 
@@ -143,12 +151,12 @@ def main():
     lab_dev = [t.to(device) for t in labs]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
     # the pre-staged batches stay resident: with --graph one graph per batch buffer, replayed without copies
-    for i in range(max(args.warmup, nb if args.graph else 0)):
+    for i in range(max(args.warmup, nb if eng.use_graph else 0)):
         eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
     torch.cuda.synchronize()
     barrier()
@@ -185,7 +193,7 @@ def main():
         eng.use_graph = was_graph
     summ = timer.summary()
     final_loss = float(loss.item())
-    if world > 1:
+    if use_dist:
         eng.check()          # bucket overflow / index range flags of the exchange (device sync, outside the timing)
 
     if world > 1:
@@ -273,7 +281,7 @@ def main():
             "kernels": kernels[:12], "final_loss": final_loss,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

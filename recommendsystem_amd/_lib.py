@@ -158,5 +158,10 @@ def require_cuda(*tensors):
                           "(the package has no CPU fallback)")
 
 
+n_calls = 0      # entry-point calls so far (lets a graph recorder tell an empty segment from one with launches)
+
+
 def call(name: str, *args):
+    global n_calls
+    n_calls += 1
     check(getattr(lib(), name)(*args), name)

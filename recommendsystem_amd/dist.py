@@ -86,9 +86,20 @@ class Comm:
         self.stage_cpu = stage_cpu
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.recorder = None         # set while a step is being recorded as HIP-graph segments (see _SegmentRecorder)
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
         """Equal split: chunk s of `inp` goes to rank s; chunk s of `out` comes from rank s."""
+        if self.recorder is not None:
+            return self.recorder.collective(lambda: self._all_to_all(out, inp))
+        self._all_to_all(out, inp)
+
+    def all_reduce(self, t: torch.Tensor):
+        if self.recorder is not None:
+            return self.recorder.collective(lambda: self._all_reduce(t))
+        self._all_reduce(t)
+
+    def _all_to_all(self, out, inp):
         if self.stage_cpu and inp.is_cuda:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o.view(-1), inp.cpu().view(-1), group=self.group)
@@ -96,7 +107,7 @@ class Comm:
         else:
             dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
 
-    def all_reduce(self, t: torch.Tensor):
+    def _all_reduce(self, t):
         if self.stage_cpu and t.is_cuda:
             c = t.cpu()
             dist.all_reduce(c, group=self.group)
@@ -117,6 +128,49 @@ class Comm:
         outs = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(outs, src.contiguous(), group=self.group)
         return [o.to(t.device) for o in outs]
+
+
+class _SegmentRecorder:
+    """Records one training step as alternating HIP-graph segments and collectives.
+
+    The kernels between two collectives are captured into a HIP graph; the collectives themselves stay ordinary
+    torch.distributed calls issued between the graph replays (nothing of RCCL is captured).  All segments share
+    one memory pool, and every buffer a collective touches is a persistent tensor, so a replay is
+    graph, collective, graph, ... in the recorded order."""
+
+    def __init__(self, pool):
+        self.pool = pool
+        self.plan = []           # ("graph", CUDAGraph) | ("call", closure)
+        self._g = None
+
+    def begin(self):
+        from . import _lib
+        self._calls_at_begin = _lib.n_calls
+        self._g = torch.cuda.CUDAGraph()
+        # thread-local capture mode: the process group's watchdog thread polls its events from another thread, which
+        # must not invalidate this capture
+        self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self):
+        self._g.capture_end()
+        self.plan.append(("graph", self._g))
+        self._g = None
+
+    def collective(self, fn):
+        from . import _lib
+        if self.plan and self.plan[-1][0] == "call" and _lib.n_calls == self._calls_at_begin:
+            self.plan.append(("call", fn))  # two collectives back to back: nothing to capture between them
+            return
+        self.end()
+        self.plan.append(("call", fn))      # not executed while recording: no rank runs it, so the ranks stay in step
+        self.begin()
+
+    def replay(self):
+        for kind, obj in self.plan:
+            if kind == "graph":
+                obj.replay()
+            else:
+                obj()
 
 
 # -------------------------------------------------------------------------------------------------
@@ -256,12 +310,10 @@ class DistributedTrainer(FusedTrainer):
                  bucket_slack: float = 1.5, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
-        if use_graph:
-            use_graph = False            # collectives run between kernel segments; the step is issued eagerly
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
-        super().__init__(model, mode="sparse", use_graph=False, **kw)
+        super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
@@ -335,6 +387,53 @@ class DistributedTrainer(FusedTrainer):
         ex = self._ex[plan.cap]
         ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
                     self.shard1_m, self.shard1_v)
+
+    # ---- HIP-graph segments between the collectives --------------------------------------------------
+    def _capture(self, idx, labels):
+        """Record one step reading `idx`/`labels` in place as graph segments + collectives; the training state is
+        left as it was (the warm-up steps run for real -- collectives included, on every rank -- and are undone)."""
+        ent = {"idx": idx, "labels": labels}
+        snap = [(t, t.clone()) for t in self._mutable_state()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), ops.use_workspace(self.ws):
+            for _ in range(2):
+                self._step_impl(idx, labels)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in snap:
+            t.copy_(c)
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        rec = _SegmentRecorder(self._graph_pool)
+        with torch.cuda.stream(s), ops.use_workspace(self.ws):
+            self.comm.recorder = rec
+            try:
+                rec.begin()
+                ent["loss"] = self._step_impl(idx, labels)
+                rec.end()
+            finally:
+                self.comm.recorder = None
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, c in snap:
+            t.copy_(c)
+
+        class _Replay:
+            def __init__(self, r):
+                self.r = r
+
+            def replay(self):
+                self.r.replay()
+        ent["graph"] = _Replay(rec)
+        return ent
+
+    def _mutable_state(self):
+        ts = super()._mutable_state()
+        for x in (self.shard, self.shard1, self.shard_m, self.shard_v, self.shard1_m, self.shard1_v):
+            if x is not None:
+                ts.append(x)
+        return ts
 
     # ---- utilities ---------------------------------------------------------------------------------
     def sync_to_model(self):

@@ -1,7 +1,7 @@
 """One rank of the multi-process tests (started by test_dist_cpu.py / test_dist_gpu.py).
 
     python dist_worker.py cpu <outdir>     host-side exchange protocol under gloo with torch-CPU stand-in kernels
-    python dist_worker.py gpu <outdir> <kind> <optimizer>
+    python dist_worker.py gpu <outdir> <kind> <optimizer> [graph]
                                            DistributedTrainer on cuda:0 (all ranks share the one GPU of the
                                            test box), gloo with host staging in place of RCCL
 
@@ -122,7 +122,7 @@ def run_cpu(outdir):
     open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
 
 
-def run_gpu(outdir, kind, optimizer):
+def run_gpu(outdir, kind, optimizer, use_graph=False):
     from recommendsystem_amd import data, models
     from recommendsystem_amd.base_model import random_all
     from recommendsystem_amd.dist import DistributedTrainer
@@ -147,11 +147,11 @@ def run_gpu(outdir, kind, optimizer):
             if p.dim() == 2 and p.shape[0] in vocab:
                 p[1:].normal_(0, 0.05)
     m.train()
-    eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
+    eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
     losses = []
     for s in range(steps):
         idx, y = rank_batch(rank + 10 * s, vocab, batch, zero_every=17)
-        loss = eng.step_tensors(idx.cuda(), y.cuda())
+        loss = eng.step_tensors(idx.cuda(), y.cuda())      # with use_graph: recorded once, then replayed with copies
         losses.append(float(loss.item()))
     eng.check()
     eng.sync_to_model()
@@ -169,6 +169,6 @@ if __name__ == "__main__":
         if mode == "cpu":
             run_cpu(outdir)
         else:
-            run_gpu(outdir, sys.argv[3], sys.argv[4])
+            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=len(sys.argv) > 5 and sys.argv[5] == "graph")
     finally:
         dist.destroy_process_group()

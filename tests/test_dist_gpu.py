@@ -45,11 +45,13 @@ def single_gpu_reference(kind, optimizer, world):
     return m, losses
 
 
-@pytest.mark.parametrize("kind,optimizer", [("deepfm", "SGD"), ("deepfm", "Adam"), ("fm", "Adagrad"), ("lr", "AdamW"),
-                                            ("dnn", "Adam")])
-def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, tmp_path):
+@pytest.mark.parametrize("kind,optimizer,graph", [("deepfm", "SGD", False), ("deepfm", "Adam", False), ("fm", "Adagrad", False),
+                                                  ("lr", "AdamW", False), ("dnn", "Adam", False),
+                                                  ("deepfm", "Adam", True), ("fm", "SGD", True)])
+def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, graph, tmp_path):
+    """graph=True: the step is replayed as HIP-graph segments with the collectives issued between them."""
     world = 2
-    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer], timeout=200)
+    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer] + (["graph"] if graph else []), timeout=200)
     assert codes == [0] * world, "\n".join(outs)
     got = np.load(tmp_path / "state.npz")
     m, losses = single_gpu_reference(kind, optimizer, world)
