@@ -123,3 +123,104 @@ def synthetic_batches(vocab_sizes, batch: int, n_batches: int, device, seed: int
         idxs.append(idx.to(device))
         labels.append(y.to(device))
     return idxs, labels
+
+
+# -------------------------------------------------------------------------------------------------
+# On-disk formats of the reference's preprocessing output
+# -------------------------------------------------------------------------------------------------
+def build_encoding_map(values) -> (dict, int):
+    """Frequency-sorted vocabulary of one categorical column (model/utils/Tokenizer.py:70-82).
+
+    Tokens are ranked by (-count, str(token)); index 0 is PAD (token -1), ranks start at 1, and one more index
+    -- the last -- is reserved for out-of-vocabulary values (token -2).  Returns (map, vocab_size) with
+    vocab_size counting PAD and OOV, which is the `vocab_size` written to feature_map.json."""
+    from collections import Counter
+    word_counts = sorted(((str(k), int(v)) for k, v in Counter(values).items()), key=lambda x: (-x[1], x[0]))
+    enc = {-1: 0}
+    enc.update({int(tok): i for i, (tok, _) in enumerate(word_counts, 1)})
+    n = len(enc)
+    enc[-2] = n
+    return enc, n + 1
+
+
+def encode_column(values, encoding_map: dict) -> torch.Tensor:
+    """Token -> index with unseen tokens sent to the OOV index (the map's entry for -2)."""
+    oov = encoding_map[-2]
+    return torch.tensor([encoding_map.get(int(v), oov) for v in values], dtype=torch.int64)
+
+
+class EncodedTable:
+    """One split of the reference's encoded data: checkpoint/encoded_column/<split>/encoded_table.parquet
+    (model/utils/PreProcess.py:61-72), held as ONE columnar int64 matrix [F, N] in pinned host memory plus the
+    label vector, so a training batch is a contiguous [F, B] slice and reaches the GPU in one copy (the reference
+    moves 40 per-column tensors per step, model/utils/BaseModel.py:204-208)."""
+
+    def __init__(self, columns: Sequence[str], matrix: torch.Tensor, labels: torch.Tensor, label_col: str = "label"):
+        self.columns = list(columns)
+        self.matrix = matrix          # [F, N] int64
+        self.labels = labels          # [N]
+        self.label_col = label_col
+
+    @classmethod
+    def from_parquet(cls, path: str, columns: Sequence[str], label_col: str = "label", pin: bool = True):
+        import pyarrow.parquet as pq
+        table = pq.read_table(path, columns=list(columns) + [label_col])
+        n = table.num_rows
+        mat = torch.empty((len(columns), n), dtype=torch.int64)
+        for i, c in enumerate(columns):
+            mat[i] = torch.from_numpy(table.column(c).to_numpy(zero_copy_only=False).astype("int64", copy=True))
+        lab = torch.from_numpy(table.column(label_col).to_numpy(zero_copy_only=False).astype("int64", copy=True))
+        if pin and torch.cuda.is_available():
+            mat, lab = mat.pin_memory(), lab.pin_memory()
+        return cls(columns, mat, lab, label_col)
+
+    def __len__(self):
+        return self.matrix.shape[1]
+
+    def loader(self, batch_size: int, device=None, drop_last: bool = False):
+        return EncodedLoader(self, batch_size, device, drop_last)
+
+
+class EncodedLoader:
+    """Sequential batches of an EncodedTable in the reference's (inputs, labels) format.  With `device` set, every
+    batch is moved with one non-blocking copy of its [F, B] slice and the per-column tensors are views of it."""
+
+    def __init__(self, table: EncodedTable, batch_size: int, device=None, drop_last: bool = False):
+        self.table, self.batch_size, self.device, self.drop_last = table, int(batch_size), device, drop_last
+
+    def __len__(self):
+        n = len(self.table)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        t = self.table
+        for b in range(len(self)):
+            lo, hi = b * self.batch_size, min((b + 1) * self.batch_size, len(t))
+            idx, y = t.matrix[:, lo:hi], t.labels[lo:hi]
+            if self.device is not None:
+                idx = idx.contiguous().to(self.device, non_blocking=True)
+                y = y.to(self.device, non_blocking=True)
+            inputs = {c: idx[i] for i, c in enumerate(t.columns)}
+            inputs[t.label_col] = y
+            yield inputs, {t.label_col: y}
+
+
+def load_encoded_checkpoint(root: str, embedding_dim: int, batch_size: int, device=None, label_col: str = "label",
+                            splits=("train", "valid", "test")) -> Recorder:
+    """Recorder over a reference checkpoint directory: `<root>/feature_map.json` (column -> {"type", "vocab_size"},
+    Tokenizer.py:58-60) and `<root>/encoded_column/<split>/encoded_table.parquet`.  `features` is categorical
+    columns then numerical ones (PreProcess.py:46); only categorical columns are read into the index matrix."""
+    import json
+    import os
+    with open(os.path.join(root, "feature_map.json"), "r", encoding="utf-8") as f:
+        feature_map = json.load(f)
+    cat = [c for c, info in feature_map.items() if info["type"] == "categorical"]
+    num = [c for c, info in feature_map.items() if info["type"] == "numerical"]
+    rec = Recorder(feature_map, cat + num, embedding_dim, batch_size, label_col=label_col)
+    for split in splits:
+        path = os.path.join(root, "encoded_column", split, "encoded_table.parquet")
+        if not os.path.exists(path):
+            continue
+        loader = EncodedTable.from_parquet(path, cat, label_col).loader(batch_size, device)
+        setattr(rec, f"{split}_loader", loader)
+    return rec
