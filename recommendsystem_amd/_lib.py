@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librs_hip.so")
+LIB_PATH = os.environ.get("RS_HIP_LIB") or os.path.join(_HERE, "lib", "librs_hip.so")   # RS_HIP_LIB: experiment builds
 
 c_i64p = C.c_void_p
 c_f32p = C.c_void_p

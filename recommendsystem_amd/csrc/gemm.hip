@@ -22,6 +22,7 @@
 // k); the next tile's global loads are issued before the MFMAs of the current tile and written to
 // the other LDS buffer after them (one barrier per k-tile).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -40,7 +41,17 @@ struct GemmArgs {
     float* ws;              // [splitk, M, N] partial slabs when splitk > 1
     float* cs_part;         // [ceil(M / (BM/2)), N] or null: column sums of the finished C per wave row
                             // (partial bias gradients when C is a dZ), added up by rs_colsum_finish_multi
+    int vec_epi;            // C (and mulsrc, bias) allow float4 access: the LDS-staged epilogue is used
+    unsigned* trace;        // experiment builds: per-wave cycle counters (see RS_GEMM_DBG bit 64)
+    int dbg;                // ablation experiments (builds with -DRS_GEMM_EXPERIMENT read RS_GEMM_DBG):
+                            // 1 = no DMA in the k loop, 2 = no stores, 4 = no MFMA, 8 = no barrier in the k loop,
+                            // 16 = no LDS fragment reads after the first k-tile
 };
+#ifdef RS_GEMM_EXPERIMENT
+#define RS_DBG(g) ((g).dbg)
+#else
+#define RS_DBG(g) 0
+#endif
 
 __device__ __forceinline__ float act_grad_from_h(int act, float h) {
     switch (act) {
@@ -83,7 +94,7 @@ __device__ __forceinline__ void tile_coords(int& tm, int& tn) {
 // splitk  > 1: raw slab store (splitk_reduce_kernel adds the slabs and applies the epilogue).
 template <int BM, int BN>
 __device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0, int wm0,
-                                            int wn0, int li, int lh) {
+                                            int wn0, int li, int lh, int wid, float* smem) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const bool partial = g.splitk > 1;
     float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
@@ -108,13 +119,17 @@ __device__ __forceinline__ void finish_tile(const GemmArgs& g, f32x16 (&acc)[BM 
             }
         }
     if (partial || !g.cs_part) return;
-    const int prow = (m0 + wm0) / (BM / 2);
+    // column sums of the workgroup's BM rows: lane halves, then the two wave rows through LDS
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float t = cs[j] + __shfl_xor(cs[j], 32, 64);
-        const int n = n0 + wn0 + j * 32 + li;
-        if (lh == 0 && n < g.N && m0 + wm0 < g.M) g.cs_part[(long long)prow * g.N + n] = t;
+    for (int j = 0; j < TN; ++j) cs[j] += __shfl_xor(cs[j], 32, 64);
+    __syncthreads();                                     // the staging LDS is free
+    if (lh == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) smem[(wid >> 1) * BN + wn0 + j * 32 + li] = cs[j];
     }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BN && n0 + t < g.N) g.cs_part[(long long)(m0 / BM) * g.N + n0 + t] = smem[t] + smem[BN + t];
 }
 
 // ---- tile staging -----------------------------------------------------------------------------
@@ -235,23 +250,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    finish_tile<BM, BN>(g, acc, m0, n0, wm0, wn0, li, lh);
+    finish_tile<BM, BN>(g, acc, m0, n0, wm0, wn0, li, lh, wid, smem);
 }
 
 // =================================================================================================
-// Fast path: LDS ring filled by LDS-DMA (global_load_lds_dwordx4), three stages, two k-tiles in flight
+// Fast path: LDS ring filled by LDS-DMA (global_load_lds_dwordx4), NST stages, NST-1 k-tiles in flight
 // across the barrier, one barrier per k-tile.  No staging registers, no ds_write.
+//
+// Matrix instruction: v_mfma_f32_16x16x4_f32.  Measured on MI355X with a register-only loop
+// (tools/mfma_clock.hip): it sustains its nominal 32 cycles per SIMD (137 TFLOP/s chip-wide at the
+// 2.17 GHz the part holds under this load), while v_mfma_f32_32x32x2_f32 needs about 80 cycles for its
+// nominal 64 (about 100 TFLOP/s), whatever the number of independent accumulator chains or waves.
+// Operand roles: lane (r = lane & 15, g = lane >> 4) supplies A[row r][k_g] and B[k_g][col r]; the result
+// block has col = lane & 15, row = 4*(lane >> 4) + reg.
 //
 // LDS images (per stage, per operand, BK = 32):
 //   k-contiguous operand  ("RK"): [rows][32 k] row-major, 128 B per row, 16-byte chunks XOR-swizzled
 //                                 (chunk c of row r is stored at chunk c ^ ((r>>1)&7)); an MFMA operand
-//                                 read is one conflict-free ds_read_b128 = 4 consecutive k.
-//   m/n-contiguous operand ("KM"): [32 k][rows] as it lies in memory; operand reads are ds_read_b32.
-// The DMA writes LDS lane-linearly (wave base + lane*16 B), so the swizzle is applied to each lane's
+//                                 read is one conflict-free ds_read_b128 = 4 k-steps of one row.
+//   m/n-contiguous operand ("KM"): [32 k][rows], row positions XOR-swizzled by the k row
+//                                 (element (k, r) sits at position r ^ (((k>>2)&3) << 4)), so that the four
+//                                 lane groups of a ds_read_b32 -- four k rows 1 KiB apart -- hit different banks.
+// The DMA writes LDS lane-linearly (wave base + lane*16 B), so both swizzles are applied to each lane's
 // SOURCE address and again on the read.  Lanes whose source would fall outside the matrix (row / k
 // tails) read a 16-byte block of zeros instead.
-// k assignment inside a tile: MFMA (q, j), q = 0..3, j = 0..3, lane half h  ->  k = 8q + 4h + j, the
-// same for both operands.
+// k assignment inside a tile: half h = 0..1, step j = 0..3, lane group g  ->  k = 16h + 4g + j, the same
+// for both operands.
 __device__ __attribute__((aligned(16))) float g_zero_src[4] = {0.f, 0.f, 0.f, 0.f};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -261,7 +285,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int R, bool MC> struct DmaOp {
     static constexpr int P = R / 32;                 // DMA instructions per thread per tile
     static constexpr int BYTES = R * 32 * 4;
-    static constexpr int NREAD = MC ? 2 : 1;         // ds_read instructions per 32-row tile per q
+    static constexpr int NREAD = MC ? 2 : 1;         // ds_read instructions per 16-row block per half k-tile
 
     const float* src[P];  // this lane's 16 source bytes for the NEXT tile to issue (zeros for dead rows)
     long long step[P];    // advance per k-tile in elements (0 for dead rows)
@@ -279,7 +303,7 @@ template <int R, bool MC> struct DmaOp {
                 ok = row0 + row < rows;
                 off = (long long)(row0 + row) * ld + kbeg + c * 4;
             } else {
-                const int k = pos / (R / 4), r4 = (pos % (R / 4)) * 4;
+                const int k = pos / (R / 4), r4 = ((pos % (R / 4)) * 4) ^ (((k >> 2) & 3) << 4);
                 kofs[p] = k;
                 ok = row0 + r4 < rows;
                 off = (long long)(kbeg + k) * ld + row0 + r4;
@@ -298,34 +322,35 @@ template <int R, bool MC> struct DmaOp {
     }
 };
 
-// Operand fragments of one q step (8 k): 4 floats per 32-row tile.
+// Operand fragments of one half k-tile (16 k): 4 floats (steps j = 0..3) per 16-row block.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool MC, int T> struct Frag {
     f32x4 v[T];          // RK: one ds_read_b128
-    f32x2 s[T][2];       // KM: two ds_read2st64_b32 (k = .., ..+1 | ..+2, ..+3)
+    f32x2 s[T][2];       // KM: two ds_read2st64_b32 (steps 0,1 | 2,3)
     __device__ __forceinline__ float get(int t, int j) const {
         if constexpr (MC) return s[t][j >> 1][j & 1];
         else return v[t][j];
     }
 };
 
-// KM read of k rows (8Q + 2J) and (8Q + 2J + 1): row stride R floats = R/64 units of 64 dwords
-template <int R, int Q, int J>
+// KM read of k rows (16H + 2J) and (16H + 2J + 1) above the lane's group row: row stride R floats = R/64
+// units of 64 dwords
+template <int R, int H, int J>
 __device__ __forceinline__ void km_read2(f32x2& d, unsigned a) {
     asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3"
-                 : "=v"(d) : "v"(a), "i"((8 * Q + 2 * J) * (R / 64)), "i"((8 * Q + 2 * J + 1) * (R / 64)));
+                 : "=v"(d) : "v"(a), "i"((16 * H + 2 * J) * (R / 64)), "i"((16 * H + 2 * J + 1) * (R / 64)));
 }
 
-template <int R, bool MC, int T, int Q>
-__device__ __forceinline__ void frag_read(Frag<MC, T>& f, const unsigned (&addr)[T][4], unsigned so) {
+template <int R, bool MC, int T, int H>
+__device__ __forceinline__ void frag_read(Frag<MC, T>& f, const unsigned (&addr)[T][2], unsigned so) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if constexpr (!MC) {
-            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v[t]) : "v"(addr[t][Q] + so));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v[t]) : "v"(addr[t][H] + so));
         } else {
-            const unsigned a = addr[t][0] + so;          // includes the 4h rows of this lane half
-            km_read2<R, Q, 0>(f.s[t][0], a);
-            km_read2<R, Q, 1>(f.s[t][1], a);
+            const unsigned a = addr[t][0] + so;          // includes the 4g k rows of this lane group
+            km_read2<R, H, 0>(f.s[t][0], a);
+            km_read2<R, H, 1>(f.s[t][1], a);
         }
     }
 }
@@ -341,20 +366,122 @@ __device__ __forceinline__ void frag_pin(Frag<MC, T>& f) {
     }
 }
 
-template <int BM, int BN, bool A_MC, bool B_NC>
+// ---- epilogues for the 16x16 result blocks (same contracts as finish_tile / finish_tile_vec) ----------
+template <int BM, int BN>
+__device__ __forceinline__ void finish16(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm0, int wn0,
+                                         int lr, int lg, int wid, float* smem) {
+    constexpr int RB = BM / 32, CB = BN / 32;
+    const bool partial = g.splitk > 1;
+    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = partial ? g.N : g.ldc;
+    float cs[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) cs[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int n = n0 + wn0 + j * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm0 + i * 16 + 4 * lg + r;
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (!partial) v = epilogue(g, v, m, n);
+                    out[(long long)m * ldo + n] = v;
+                    cs[j] += v;
+                }
+            }
+        }
+    if (partial || !g.cs_part) return;
+    // column sums of the workgroup's BM rows: the four lane groups, then the two wave rows through LDS
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        cs[j] += __shfl_xor(cs[j], 16, 64);
+        cs[j] += __shfl_xor(cs[j], 32, 64);
+    }
+    if (lg == 0) {
+#pragma unroll
+        for (int j = 0; j < CB; ++j) smem[(wid >> 1) * BN + wn0 + j * 16 + lr] = cs[j];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BN && n0 + t < g.N) g.cs_part[(long long)(m0 / BM) * g.N + n0 + t] = smem[t] + smem[BN + t];
+}
+
+// 16-byte aligned outputs: the workgroup's tile goes through LDS so that every lane stores (and, for the act'
+// factor, loads) float4s and a wave covers whole 256/512-byte row segments.
+// smem: BM*(BN+4) + 4*BN floats, no longer read by any wave (the caller synchronises).
+template <int BM, int BN>
+__device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm0,
+                                             int wn0, int lr, int lg, float* smem) {
+    constexpr int RB = BM / 32, CB = BN / 32;
+    constexpr int LDT = BN + 4;                      // staged row stride (keeps float4 alignment, spreads banks)
+    constexpr int LPR = BN / 4;                      // lanes per staged row
+    constexpr int RPP = 256 / LPR;                   // rows per pass of the 256 threads
+    const bool partial = g.splitk > 1;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) smem[(wm0 + i * 16 + 4 * lg + r) * LDT + wn0 + j * 16 + lr] = acc[i][j][r];
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int c4 = (tid % LPR) * 4, rr = tid / LPR;
+    const int n = n0 + c4;
+    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    const int ldo = partial ? g.N : g.ldc;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!partial && g.bias && n < g.N) bv = *reinterpret_cast<const float4*>(g.bias + n);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        const int row = p * RPP + rr, m = m0 + row;
+        if (m < g.M && n < g.N) {
+            float4 v = *reinterpret_cast<const float4*>(smem + row * LDT + c4);
+            if (!partial) {
+                v.x = rs_act(g.act, v.x + bv.x, 0.f); v.y = rs_act(g.act, v.y + bv.y, 0.f);
+                v.z = rs_act(g.act, v.z + bv.z, 0.f); v.w = rs_act(g.act, v.w + bv.w, 0.f);
+                if (g.mulsrc) {
+                    const float4 h = *reinterpret_cast<const float4*>(g.mulsrc + (long long)m * g.ldm + n);
+                    v.x *= act_grad_from_h(g.mul_act, h.x); v.y *= act_grad_from_h(g.mul_act, h.y);
+                    v.z *= act_grad_from_h(g.mul_act, h.z); v.w *= act_grad_from_h(g.mul_act, h.w);
+                }
+            }
+            *reinterpret_cast<float4*>(out + (long long)m * ldo + n) = v;
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
+    }
+    if (partial || !g.cs_part) return;
+    // column sums: rows of one wave (lanes LPR apart), then the four waves through LDS
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+        cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+    }
+    float* red = smem + BM * LDT;                    // [4][BN]
+    if ((tid & 63) < LPR) *reinterpret_cast<float4*>(red + (tid >> 6) * BN + c4) = cs;
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N)
+        g.cs_part[(long long)(m0 / BM) * g.N + n0 + tid] = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+}
+
+template <int BM, int BN, bool A_MC, bool B_NC, int NST>
 __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     using DA = DmaOp<BM, A_MC>;
     using DB = DmaOp<BN, B_NC>;
-    constexpr int NST = 3;
+    constexpr int DIST = NST - 1;                  // k-tiles in flight ahead of the one being multiplied
     constexpr int ST_BYTES = DA::BYTES + DB::BYTES;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RB = BM / 32, CB = BN / 32;      // 16x16 result blocks per wave: (BM/2) x (BN/2) wave tile
     constexpr int NDMA = DA::P + DB::P;
-    constexpr int NRD = TM * DA::NREAD + TN * DB::NREAD;
+    constexpr int NRD_ = RB * DA::NREAD + CB * DB::NREAD;
+    constexpr int NRD = NRD_ > 15 ? 15 : NRD_;     // LDS reads complete in order: waiting for fewer is still right
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
+    const int lr = lane & 15, lg = lane >> 4;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
     int tile_m, tile_n;
     tile_coords(tile_m, tile_n);
@@ -367,37 +494,38 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     da.init(g.A, g.lda, g.M, m0, kbeg, tid);
     db.init(g.B, g.ldb, g.N, n0, kbeg, tid);
 
-    // LDS read addresses (bytes from the start of a stage)
+    // LDS read addresses (bytes from the start of a stage), per 16-row block and half k-tile
     const unsigned lds0 = (unsigned)(unsigned long long)RS_LDS_PTR(smem);
-    unsigned aA[TM][4], aB[TN][4];
+    unsigned aA[RB][2], aB[CB][2];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int r = wm0 + t * 32 + li;
+    for (int t = 0; t < RB; ++t) {
+        const int r = wm0 + t * 16 + lr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            aA[t][q] = lds0 + (A_MC ? (unsigned)(((4 * lh) * BM + r) * 4)
-                                    : (unsigned)((r * 8 + ((2 * q + lh) ^ ((r >> 1) & 7))) * 16));
+        for (int h = 0; h < 2; ++h)
+            aA[t][h] = lds0 + (A_MC ? (unsigned)(((4 * lg) * BM + (r ^ (lg << 4))) * 4)
+                                    : (unsigned)((r * 8 + ((4 * h + lg) ^ ((r >> 1) & 7))) * 16));
     }
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int r = wn0 + t * 32 + li;
+    for (int t = 0; t < CB; ++t) {
+        const int r = wn0 + t * 16 + lr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            aB[t][q] = lds0 + DA::BYTES + (B_NC ? (unsigned)(((4 * lh) * BN + r) * 4)
-                                                : (unsigned)((r * 8 + ((2 * q + lh) ^ ((r >> 1) & 7))) * 16));
+        for (int h = 0; h < 2; ++h)
+            aB[t][h] = lds0 + DA::BYTES + (B_NC ? (unsigned)(((4 * lg) * BN + (r ^ (lg << 4))) * 4)
+                                                : (unsigned)((r * 8 + ((4 * h + lg) ^ ((r >> 1) & 7))) * 16));
     }
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[RB][CB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < CB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     // DMA number `i` (0 .. NDMA-1) of k-tile kt into stage st; A's pieces first, then B's.
     auto issue_i = [&](auto ic, int kt, int st) {
         constexpr int i = decltype(ic)::value;
+        if ((RS_DBG(g) & 1) && kt >= DIST) return;
         float* base = smem + st * (ST_BYTES / 4);
         if constexpr (i < DA::P) da.template issue_one<i>(kbeg + kt * 32, kend, base, wid);
         else db.template issue_one<i - DA::P>(kbeg + kt * 32, kend, base + DA::BYTES / 4, wid);
@@ -410,69 +538,107 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
         if constexpr (NDMA > 4) { issue_i(std::integral_constant<int, 4>{}, kt, st); issue_i(std::integral_constant<int, 5>{}, kt, st); }
         if constexpr (NDMA > 6) { issue_i(std::integral_constant<int, 6>{}, kt, st); issue_i(std::integral_constant<int, 7>{}, kt, st); }
     };
-    // prologue: two tiles in flight (tiles past the end read zeros, which keeps the counts uniform)
+    // prologue: DIST tiles in flight (tiles past the end read zeros, which keeps the counts uniform)
     issue_all(0, 0);
-    issue_all(1, 1);
+    if constexpr (DIST > 1) issue_all(1, 1);
 
+#ifdef RS_GEMM_EXPERIMENT
+#define RS_CYC() ((unsigned)__builtin_amdgcn_s_memtime() & 0xFFFFF)      /* shader clock; only used where no LDS read is pending */
+    unsigned tr_start = RS_CYC(), tr_dma = 0, tr_bar = 0, tr_lds = 0, tr_first = 0;
+#define RS_TR(acc, t0) { const unsigned t1__ = RS_CYC(); acc += (t1__ - (t0)) & 0xFFFFF; t0 = t1__; }
+#else
+#define RS_TR(acc, t0)
+#endif
     auto body = [&](int kt, int st) {
-        // tile kt has landed once only the NDMA younger DMAs (tile kt+1) are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        __builtin_amdgcn_s_barrier();
+        // tile kt has landed once only the younger DMAs (tiles kt+1 .. kt+DIST-1) are outstanding
+#ifdef RS_GEMM_EXPERIMENT
+        unsigned tc = RS_CYC();
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (DIST - 1)) : "memory");
+        RS_TR(tr_dma, tc);
+        if (!(RS_DBG(g) & 8)) __builtin_amdgcn_s_barrier();
+        RS_TR(tr_bar, tc);
+#ifdef RS_GEMM_EXPERIMENT
+        if (kt == 0) tr_first = (tc - tr_start) & 0xFFFFF;
+#endif
         const unsigned so = (unsigned)(st * ST_BYTES);
-        const int nst = (st + 2) % NST;              // stage read in iteration kt-1: free after the barrier
-        Frag<A_MC, TM> fa[2];
-        Frag<B_NC, TN> fb[2];
-        // One q step: next fragments' LDS reads, wait for this step's, then TM*TN*4 MFMAs with the
-        // DMAs of k-tile kt+2 spread between them (NDMA/4 per step) so their issue overlaps MFMA time.
-        auto step = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            if constexpr (q < 3) {
-                frag_read<BM, A_MC, TM, q + 1>(fa[(q + 1) & 1], aA, so);
-                frag_read<BN, B_NC, TN, q + 1>(fb[(q + 1) & 1], aB, so);
+        const int nst = (st + DIST) % NST;           // stage read in iteration kt-1: free after the barrier
+        Frag<A_MC, RB> fa[2];
+        Frag<B_NC, CB> fb[2];
+        // One half k-tile: the other half's LDS reads, wait for this half's, then 4 steps of RB*CB MFMAs with
+        // the DMAs of k-tile kt+DIST spread between the steps so that their issue overlaps MFMA time.
+        auto half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if constexpr (h == 0) {
+                if (!((RS_DBG(g) & 16) && kt > 0)) {
+                    frag_read<BM, A_MC, RB, 1>(fa[1], aA, so);
+                    frag_read<BN, B_NC, CB, 1>(fb[1], aB, so);
+                }
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            frag_pin<A_MC, TM>(fa[q & 1]);
-            frag_pin<B_NC, TN>(fb[q & 1]);
+            frag_pin<A_MC, RB>(fa[h]);
+            frag_pin<B_NC, CB>(fb[h]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (!(RS_DBG(g) & 4)) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                    for (int tm = 0; tm < RB; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].get(tm, j), fb[q & 1].get(tn, j),
-                                                                           acc[tm][tn], 0, 0, 0);
-                // 8 issue slots per k-tile (after j = 0 and j = 2 of every q step); NDMA <= 8 of them used
-                if (j == 0 && 2 * q < NDMA) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_i(std::integral_constant<int, (2 * q < NDMA ? 2 * q : 0)>{}, kt + 2, nst);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int tn = 0; tn < CB; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[h].get(tm, j), fb[h].get(tn, j), acc[tm][tn],
+                                                                               0, 0, 0);
                 }
-                if (j == 2 && 2 * q + 1 < NDMA) {
+                // 8 issue slots per k-tile (one after every step); NDMA <= 8 of them used
+                if (4 * h + j < NDMA) {
                     __builtin_amdgcn_sched_barrier(0);
-                    issue_i(std::integral_constant<int, (2 * q + 1 < NDMA ? 2 * q + 1 : 0)>{}, kt + 2, nst);
+                    if (j == 0) issue_i(std::integral_constant<int, (4 * h + 0 < NDMA ? 4 * h + 0 : 0)>{}, kt + DIST, nst);
+                    if (j == 1) issue_i(std::integral_constant<int, (4 * h + 1 < NDMA ? 4 * h + 1 : 0)>{}, kt + DIST, nst);
+                    if (j == 2) issue_i(std::integral_constant<int, (4 * h + 2 < NDMA ? 4 * h + 2 : 0)>{}, kt + DIST, nst);
+                    if (j == 3) issue_i(std::integral_constant<int, (4 * h + 3 < NDMA ? 4 * h + 3 : 0)>{}, kt + DIST, nst);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        frag_read<BM, A_MC, TM, 0>(fa[0], aA, so);
-        frag_read<BN, B_NC, TN, 0>(fb[0], aB, so);
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-        step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{});
+        if (!((RS_DBG(g) & 16) && kt > 0)) {
+            frag_read<BM, A_MC, RB, 0>(fa[0], aA, so);
+            frag_read<BN, B_NC, CB, 0>(fb[0], aB, so);
+        }
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
     };
     for (int kt = 0; kt < nk; kt += NST) {
         body(kt, 0);
         if (kt + 1 < nk) body(kt + 1, 1);
-        if (kt + 2 < nk) body(kt + 2, 2);
+        if constexpr (NST > 2) { if (kt + 2 < nk) body(kt + 2, 2); }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the two trailing (zero) tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing (zero) tiles
+#ifdef RS_GEMM_EXPERIMENT
+    const unsigned tr_loop_end = RS_CYC();
+    if ((RS_DBG(g) & 64) && g.trace) {
+        __syncthreads();
+        if (RS_DBG(g) & 128) {} else {
+            if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem);
+            else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tr_end = RS_CYC();
+        if (lane == 0) {
+            unsigned* o = g.trace + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+            o[0] = tr_start; o[1] = tr_first; o[2] = (tr_loop_end - tr_start) & 0xFFFFF; o[3] = (tr_end - tr_start) & 0xFFFFF;
+            o[4] = tr_dma; o[5] = tr_bar; o[6] = tr_lds; o[7] = nk;
+        }
+        return;
+    }
+#endif
 
-    finish_tile<BM, BN>(g, acc, m0, n0, wm0, wn0, li, lh);
+    if (RS_DBG(g) & 2) { if (acc[0][0][0] == 12345.678f) g.C[0] = 1.f; return; }
+    __syncthreads();                                      // every wave is done reading the LDS ring
+    if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem);
+    else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem);
 }
 
 // Sum the split-K slabs in slab order and apply the epilogue.
@@ -514,10 +680,10 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     return RS_OK;
 }
 
-template <int BM, int BN, bool A_MC, bool B_NC>
+template <int BM, int BN, bool A_MC, bool B_NC, int NST = 3>
 int launch_dma(const GemmArgs& g, hipStream_t stream) {
-    constexpr size_t smem = (size_t)3 * (BM + BN) * 32 * sizeof(float);
-    auto kern = gemm_f32_dma_kernel<BM, BN, A_MC, B_NC>;
+    constexpr size_t smem = (size_t)NST * (BM + BN) * 32 * sizeof(float);
+    auto kern = gemm_f32_dma_kernel<BM, BN, A_MC, B_NC, NST>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -547,6 +713,7 @@ int dispatch(const GemmArgs& g, bool va, bool vb, int tile, hipStream_t s) {
             case 1: return launch_dma<128, 64, A_MC, B_NC>(g, s);
             case 2: return launch_dma<64, 128, A_MC, B_NC>(g, s);
             case 3: return launch_dma<64, 64, A_MC, B_NC>(g, s);
+            case 5: return launch_dma<64, 64, A_MC, B_NC, 2>(g, s);        // 64x64 with a 2-stage ring (5 workgroups/CU)
             default: return launch<64, 64, A_MC, B_NC, true, true>(g, s);   // tile 4: register-staged kernel
         }
     }
@@ -692,8 +859,8 @@ int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out) {
     return tile;
 }
 
-// Rows of the partial column sums a GEMM with tile code `tile` leaves for an M-row output (one per wave row).
-int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile == 1) ? 64 : 32); }
+// Rows of the partial column sums a GEMM with tile code `tile` leaves for an M-row output (one per tile row).
+int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile == 1) ? 128 : 64); }
 
 // C = epi(op(A) op(B)); see the header of this file for operand conventions.
 // tile < 0 and splitk <= 0 let the library choose.  workspace is needed when the resolved split count is > 1
@@ -729,7 +896,12 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
                      "rs_gemm_f32: workspace too small for splitk=%d (%zu bytes given)", splitk, workspace_bytes);
     RS_CHECK_ARG(!colsum_part || splitk == 1, "rs_gemm_f32: colsum_part needs an unsplit reduction (splitk resolved to %d)",
                  splitk);
-    GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part};
+    static const int dbg = getenv("RS_GEMM_DBG") ? atoi(getenv("RS_GEMM_DBG")) : 0;
+    static const bool allow_vec = !(getenv("RS_GEMM_VEC_EPI") && atoi(getenv("RS_GEMM_VEC_EPI")) == 0);
+    const bool vec_epi = allow_vec && N % 4 == 0 && aligned16(C) && ldc % 4 == 0 && (!bias || aligned16(bias)) &&
+                         (!mulsrc || (aligned16(mulsrc) && ldm % 4 == 0)) && (splitk == 1 || aligned16(workspace));
+    GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part,
+               vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg};
     g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
     const bool va = aligned16(A) && lda % 4 == 0 && (a_mc ? M % 4 == 0 : K % 4 == 0);

@@ -124,5 +124,8 @@ def test_model_logits_and_train_steps(kind, optimizer, kw):
                 ok = "linear.bias"
             if ok is None or not v.dtype.is_floating_point:
                 continue
-            torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=5e-6, msg=lambda s, k=k: f"{k} after step {step}: {s}")
+            # Adam divides by sqrt(v): where a gradient is itself at rounding level the step (lr = 1e-2) amplifies the
+            # difference in summation order, so its absolute floor is a fraction of lr
+            atol = 5e-5 if optimizer in ("Adam", "AdamW") else 5e-6
+            torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
     m.embedding_layer._tab.layout.check_indices()
