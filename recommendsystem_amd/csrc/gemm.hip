@@ -287,38 +287,54 @@ template <int R, bool MC> struct DmaOp {
     static constexpr int BYTES = R * 32 * 4;
     static constexpr int NREAD = MC ? 2 : 1;         // ds_read instructions per 16-row block per half k-tile
 
-    const float* src[P];  // this lane's 16 source bytes for the NEXT tile to issue (zeros for dead rows)
-    long long step[P];    // advance per k-tile in elements (0 for dead rows)
-    int kofs[P];          // this lane's k offset inside a tile
+    // A lane's source address for k-tile t is  base + t*step + voff[p]  with base and step uniform over the
+    // workgroup (scalar registers) and voff a fixed per-lane byte offset, so issuing a DMA costs no vector
+    // arithmetic.  Rows past the end of the matrix are clamped to its last rows: what they load only feeds
+    // result rows/columns that are never stored.
+    const char* base;
+    long long step;       // bytes per k-tile
+    unsigned voff[P];
+    int kofs[P];          // this lane's k offset inside a tile (for the K tail)
 
     __device__ __forceinline__ void init(const float* __restrict__ Pm, int ld, int rows, int row0, int kbeg, int tid) {
+        if constexpr (!MC) {
+            base = reinterpret_cast<const char*>(Pm + (long long)row0 * ld + kbeg);
+            step = 32 * 4;
+        } else {
+            base = reinterpret_cast<const char*>(Pm + (long long)kbeg * ld + row0);
+            step = (long long)32 * ld * 4;
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int pos = p * 256 + tid;
-            bool ok;
-            long long off;
             if constexpr (!MC) {
                 const int row = pos >> 3, cp = pos & 7, c = cp ^ ((row >> 1) & 7);
                 kofs[p] = c * 4;
-                ok = row0 + row < rows;
-                off = (long long)(row0 + row) * ld + kbeg + c * 4;
+                const int rc = min(row, rows - 1 - row0);
+                voff[p] = (unsigned)(rc * ld + c * 4) * 4u;
             } else {
                 const int k = pos / (R / 4), r4 = ((pos % (R / 4)) * 4) ^ (((k >> 2) & 3) << 4);
                 kofs[p] = k;
-                ok = row0 + r4 < rows;
-                off = (long long)(kbeg + k) * ld + row0 + r4;
+                const int rc = min(r4, rows - 4 - row0);
+                voff[p] = (unsigned)(k * ld + rc) * 4u;
             }
-            src[p] = ok ? Pm + off : g_zero_src;
-            step[p] = ok ? (MC ? (long long)32 * ld : 32) : 0;
         }
     }
-    // Issue DMA number p of the next tile into the operand image at `dst`, then advance.
-    // k0 = first k of that tile; lanes past kend read zeros.
-    template <int p>
-    __device__ __forceinline__ void issue_one(int k0, int kend, float* dst, int wid) {
-        const float* s = (k0 + kofs[p] < kend) ? src[p] : g_zero_src;
-        __builtin_amdgcn_global_load_lds(RS_GLB_PTR(s), RS_LDS_PTR(dst + (p * 256 + wid * 64) * 4), 16, 0, 0);
-        src[p] += step[p];
+    // Issue DMA number p of k-tile t into the operand image at LDS byte address `dst` (uniform).
+    // FULL: the tile lies inside [kbeg, kend): scalar base + per-lane offset, no predicate.
+    // Otherwise lanes whose k is past kend read zeros (first k of the tile = k0).
+    template <int p, bool FULL>
+    __device__ __forceinline__ void issue_one(int t, int k0, int kend, unsigned dst, int wid) {
+        const char* cur = base + (long long)t * step;
+        const unsigned d = dst + (unsigned)((p * 256 + wid * 64) * 16);
+        if constexpr (FULL) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(d), "v"(voff[p]), "s"(cur) : "memory");
+        } else {
+            const char* s = (k0 + kofs[p] < kend) ? cur + voff[p] : reinterpret_cast<const char*>(g_zero_src);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(d), "v"(s) : "memory");
+        }
     }
 };
 
@@ -523,20 +539,22 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     // DMA number `i` (0 .. NDMA-1) of k-tile kt into stage st; A's pieces first, then B's.
-    auto issue_i = [&](auto ic, int kt, int st) {
+    auto issue_i = [&](auto ic, auto fullc, int kt, int st) {
         constexpr int i = decltype(ic)::value;
+        constexpr bool FULL = decltype(fullc)::value;
         if ((RS_DBG(g) & 1) && kt >= DIST) return;
-        float* base = smem + st * (ST_BYTES / 4);
-        if constexpr (i < DA::P) da.template issue_one<i>(kbeg + kt * 32, kend, base, wid);
-        else db.template issue_one<i - DA::P>(kbeg + kt * 32, kend, base + DA::BYTES / 4, wid);
+        const unsigned base = lds0 + (unsigned)(st * ST_BYTES);
+        if constexpr (i < DA::P) da.template issue_one<i, FULL>(kt, kbeg + kt * 32, kend, base, wid);
+        else db.template issue_one<i - DA::P, FULL>(kt, kbeg + kt * 32, kend, base + DA::BYTES, wid);
     };
     auto issue_all = [&](int kt, int st) {
-        issue_i(std::integral_constant<int, 0>{}, kt, st);
-        issue_i(std::integral_constant<int, 1>{}, kt, st);
-        issue_i(std::integral_constant<int, 2>{}, kt, st);
-        issue_i(std::integral_constant<int, 3>{}, kt, st);
-        if constexpr (NDMA > 4) { issue_i(std::integral_constant<int, 4>{}, kt, st); issue_i(std::integral_constant<int, 5>{}, kt, st); }
-        if constexpr (NDMA > 6) { issue_i(std::integral_constant<int, 6>{}, kt, st); issue_i(std::integral_constant<int, 7>{}, kt, st); }
+        constexpr std::false_type F{};
+        issue_i(std::integral_constant<int, 0>{}, F, kt, st);
+        issue_i(std::integral_constant<int, 1>{}, F, kt, st);
+        issue_i(std::integral_constant<int, 2>{}, F, kt, st);
+        issue_i(std::integral_constant<int, 3>{}, F, kt, st);
+        if constexpr (NDMA > 4) { issue_i(std::integral_constant<int, 4>{}, F, kt, st); issue_i(std::integral_constant<int, 5>{}, F, kt, st); }
+        if constexpr (NDMA > 6) { issue_i(std::integral_constant<int, 6>{}, F, kt, st); issue_i(std::integral_constant<int, 7>{}, F, kt, st); }
     };
     // prologue: DIST tiles in flight (tiles past the end read zeros, which keeps the counts uniform)
     issue_all(0, 0);
@@ -549,7 +567,9 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
 #else
 #define RS_TR(acc, t0)
 #endif
-    auto body = [&](int kt, int st) {
+    // One k-tile.  FULL: the tile issued during it (kt + DIST) lies entirely inside the k range.
+    auto body = [&](auto fullc, int kt, int st) {
+        constexpr std::integral_constant<bool, decltype(fullc)::value> FC{};
         // tile kt has landed once only the younger DMAs (tiles kt+1 .. kt+DIST-1) are outstanding
 #ifdef RS_GEMM_EXPERIMENT
         unsigned tc = RS_CYC();
@@ -594,10 +614,10 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
                 // 8 issue slots per k-tile (one after every step); NDMA <= 8 of them used
                 if (4 * h + j < NDMA) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j == 0) issue_i(std::integral_constant<int, (4 * h + 0 < NDMA ? 4 * h + 0 : 0)>{}, kt + DIST, nst);
-                    if (j == 1) issue_i(std::integral_constant<int, (4 * h + 1 < NDMA ? 4 * h + 1 : 0)>{}, kt + DIST, nst);
-                    if (j == 2) issue_i(std::integral_constant<int, (4 * h + 2 < NDMA ? 4 * h + 2 : 0)>{}, kt + DIST, nst);
-                    if (j == 3) issue_i(std::integral_constant<int, (4 * h + 3 < NDMA ? 4 * h + 3 : 0)>{}, kt + DIST, nst);
+                    if (j == 0) issue_i(std::integral_constant<int, (4 * h + 0 < NDMA ? 4 * h + 0 : 0)>{}, FC, kt + DIST, nst);
+                    if (j == 1) issue_i(std::integral_constant<int, (4 * h + 1 < NDMA ? 4 * h + 1 : 0)>{}, FC, kt + DIST, nst);
+                    if (j == 2) issue_i(std::integral_constant<int, (4 * h + 2 < NDMA ? 4 * h + 2 : 0)>{}, FC, kt + DIST, nst);
+                    if (j == 3) issue_i(std::integral_constant<int, (4 * h + 3 < NDMA ? 4 * h + 3 : 0)>{}, FC, kt + DIST, nst);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -610,10 +630,18 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
         half(std::integral_constant<int, 0>{});
         half(std::integral_constant<int, 1>{});
     };
-    for (int kt = 0; kt < nk; kt += NST) {
-        body(kt, 0);
-        if (kt + 1 < nk) body(kt + 1, 1);
-        if constexpr (NST > 2) { if (kt + 2 < nk) body(kt + 2, 2); }
+    // Steady state: groups of NST k-tiles whose look-ahead tiles are all full (no predicates, compile-time
+    // stages); then the remaining tiles one by one, predicated only when their look-ahead tile is not full.
+    const int nfull = (kend - kbeg) / 32;
+    int kt = 0;
+    for (; kt + NST - 1 + DIST < nfull; kt += NST) {
+        body(std::true_type{}, kt, 0);
+        body(std::true_type{}, kt + 1, 1);
+        if constexpr (NST > 2) body(std::true_type{}, kt + 2, 2);
+    }
+    for (; kt < nk; ++kt) {
+        if (kt + DIST < nfull) body(std::true_type{}, kt, kt % NST);
+        else body(std::false_type{}, kt, kt % NST);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing (zero) tiles
 #ifdef RS_GEMM_EXPERIMENT
