@@ -868,23 +868,22 @@ size_t rs_gemm_workspace_bytes(int M, int N, int splitk) {
 }
 
 // Tile/split choice for a problem on a device with `cus` compute units.
-// Returns tile code (0:128x128 1:128x64 2:64x128 3:64x64) and writes the split count.
+// Returns the tile code (0: 128x128, 1: 128x64, 2: 64x128, 3: 64x64, all with a 3-stage ring; 4: the
+// register-staged 64x64 kernel; 5: 64x64 with a 2-stage ring) and writes the split count.
 int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out) {
-    // Measured on MI355X at the MLP shapes of this workload (M or K = 4096, N, K in 256..1024): the
-    // 64x64 tile (3 workgroups per CU) is never slower than the larger tiles by more than 3 %, and
-    // fills the chip on the narrow layers.  The reduction is split when the tile grid alone leaves
-    // CUs idle and each slice still gets at least 512 of k.
-    const int tile = 3;
+    // Measured on MI355X at the MLP shapes of this workload (M or K = 4096; N, K in 256..1024), tools/gemm_tiles.py:
+    // unsplit products run best on 64x64 tiles with the 2-stage ring (32 KiB of LDS: five workgroups per CU, so
+    // the 1024-tile layers finish in one round); products whose tile grid leaves CUs idle split the reduction
+    // into a power-of-two number of slices so that about three workgroups per CU exist, each slice keeping at
+    // least 512 of k, and use the deeper 3-stage ring.
     const long long blocks = (long long)rs_cdiv(M, 64) * rs_cdiv(N, 64);
     int sk = 1;
     if (blocks < 2LL * cus && K >= 1024) {
-        sk = (int)((4LL * cus + blocks - 1) / blocks);
-        if (sk > K / 512) sk = K / 512;
-        if (sk > 16) sk = 16;
-        if (sk < 1) sk = 1;
+        const long long want = (3LL * cus + blocks - 1) / blocks;
+        while (sk * 2 <= want && sk * 2 <= K / 512 && sk * 2 <= 16) sk *= 2;
     }
     *splitk_out = sk;
-    return tile;
+    return sk > 1 ? 3 : 5;
 }
 
 // Rows of the partial column sums a GEMM with tile code `tile` leaves for an M-row output (one per tile row).

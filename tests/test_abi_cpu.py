@@ -41,9 +41,9 @@ def test_host_side_queries():
     assert h.rs_gemm_workspace_bytes(100, 50, 4) == 4 * 100 * 50 * 4
     assert h.rs_gemm_workspace_bytes(100, 50, 1) == 0
     sk = ctypes.c_int(0)
-    assert h.rs_gemm_plan(4096, 1024, 624, 256, ctypes.byref(sk)) == 3 and sk.value == 1
-    h.rs_gemm_plan(256, 512, 4096, 256, ctypes.byref(sk))
-    assert 1 < sk.value <= 16
+    assert h.rs_gemm_plan(4096, 1024, 624, 256, ctypes.byref(sk)) == 5 and sk.value == 1
+    assert h.rs_gemm_plan(256, 512, 4096, 256, ctypes.byref(sk)) == 3 and sk.value == 8
+    assert h.rs_gemm_plan(512, 1024, 4096, 256, ctypes.byref(sk)) == 3 and sk.value == 4
 
 
 def test_argument_errors_do_not_need_a_gpu():

@@ -46,7 +46,7 @@ def test_gemm_layouts(M, N, K, layout):
     _check(got, want, bound)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("splitk", [1, 3, 8])
 def test_gemm_tiles_and_splitk(tile, splitk):
     from recommendsystem_amd import ops
@@ -127,7 +127,7 @@ def test_mfma_fragment_layout_with_asymmetric_data():
 
 @pytest.mark.parametrize("M,N,K", [(4096, 1024, 512), (4096, 512, 256), (300, 200, 64), (64, 64, 32), (130, 70, 40),
                                    (1000, 37, 128), (33, 5, 7)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_gemm_colsum_byproduct(M, N, K, tile):
     """Column sums of the stored C (after the epilogue) as a by-product, e.g. db of the dZ a dX-GEMM produces;
     several producers are finished by one launch."""

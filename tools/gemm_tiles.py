@@ -26,10 +26,10 @@ def bench(lay, M, N, K, tile, sk, reps=30):
 
 for lay, M, N, K in SHAPES:
     row = []
-    sks = [1] if lay != "TN" else [8]
+    sks = [1] if lay != "TN" else [2, 4, 8, 16]
     if lay != "TN" and K >= 512 and M * N <= 4096 * 512:
-        sks = [1]
-    for tile in (3,):
+        sks = [1, 2]
+    for tile in (0, 1, 2, 3, 5):
         for sk in sks:
             us = bench(lay, M, N, K, tile, sk)
             row.append(f"t{tile}/k{sk}:{us:6.1f}")
