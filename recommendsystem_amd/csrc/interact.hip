@@ -121,6 +121,110 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_kernel(const float* __restr
     }
 }
 
+// Matrix-core form of the two kernels above for F <= 64 fields and d in {4, 8, 16, 32}: the inner products of a
+// sample are the upper triangle of its Gram matrix E E^T (E = [F, d]), the gradient is Gs E with Gs the symmetric
+// zero-diagonal matrix holding dP.  One wave per sample, v_mfma_f32_16x16x4_f32 on 16-field blocks.
+// Operand convention of the instruction: lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16]; it receives
+// C[4 * (l / 16) + v][l % 16], v = 0..3.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Forward: lane (r, g) loads the float4 E[16I + r][4(g + 4q) ..] of every field block I (one coalesced 1 KB read per
+// block); component s of that float4 serves as the lane's k-slot of MFMA step (q, s) for the A and the B operand
+// alike (the summation index may be visited in any order as long as both operands agree).
+template <int NB, int D>
+__global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __restrict__ emb, int B, int F,
+                                                                 float* __restrict__ out) {
+    constexpr int NV = D >= 16 ? D / 16 : 1;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int nwaves = gridDim.x * 4;
+    const int fd = F * D, P = F * (F - 1) / 2;
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
+        const float* e = emb + (long long)b * fd;
+        float v[NB][NV][4];
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int row = 16 * I + r, c = g + 4 * q;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < F && c < D / 4) t = *reinterpret_cast<const float4*>(e + row * D + 4 * c);
+                v[I][q][0] = t.x; v[I][q][1] = t.y; v[I][q][2] = t.z; v[I][q][3] = t.w;
+            }
+        float* o = out + (long long)b * P;
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = I; J < NB; ++J) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I][q][s4], v[J][q][s4], acc, 0, 0, 0);
+                const int j = 16 * J + r;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = 16 * I + 4 * g + t;
+                    if (i < j && j < F) o[pair_start(i, F) + j - i - 1] = acc[t];
+                }
+            }
+    }
+}
+
+// Backward: demb = Gs E.  A operand of step s, row block I: Gs[16I + r][4s + g], gathered from the sample's dP row
+// through pair slots that do not depend on the sample (computed once per wave); B operand: E[4s + g][16c + r].
+template <int NB, int D>
+__global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                                 int B, int F, float* __restrict__ demb) {
+    constexpr int KS = NB * 4;
+    constexpr int NC = D >= 16 ? D / 16 : 1;
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const int nwaves = gridDim.x * 4;
+    const int fd = F * D, P = F * (F - 1) / 2;
+    int slot[NB][KS];
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+            const int i = 16 * I + r, k = 4 * s4 + g;
+            slot[I][s4] = (i < F && k < F && i != k) ? pair_index_any(i, k, F) : -1;
+        }
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
+        const float* e = emb + (long long)b * fd;
+        const float* gs = dout + (long long)b * P;
+        float bv[KS][NC];
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int k = 4 * s4 + g, col = 16 * c + r;
+                bv[s4][c] = (k < F && col < D) ? e[k * D + col] : 0.f;
+            }
+        float* o = demb + (long long)b * fd;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            f32x4 acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < KS; ++s4) {
+                if (4 * s4 < F) {
+                    const float a = slot[I][s4] >= 0 ? gs[slot[I][s4]] : 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s4][c], acc[c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 16 * I + 4 * g + t, col = 16 * c + r;
+                    if (row < F && col < D) o[row * D + col] = acc[c][t];
+                }
+        }
+    }
+}
+
 // ---- PNN outer product (model/PNN/PNN.py:80-103) --------------------------------------------------
 // out[b, p, a, c] = e_i[a] * e_j[c] for pair p = (i, j).  One workgroup per sample, the (i, j) table of
 // all pairs in LDS; the kernel is bound by the HBM write of P*d*d floats per sample.
@@ -207,68 +311,76 @@ __global__ __launch_bounds__(256) void dcn_cross_fwd_kernel(const float* __restr
     for (int n = lane; n < D; n += 64) out[(long long)b * D + n] = x[n];
 }
 
-// Backward of the cross network.  One wave per workgroup walks samples b, b+G, ...; parameter gradients
-// accumulate in lane-private LDS words and leave as one partial row per workgroup:
-// partials[g] = [dW (L*D) | dB (L*D)], summed over g by the caller (rs_colsum_f32) in fixed order.
-__global__ __launch_bounds__(64) void dcn_cross_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ S,
-                                                           const float* __restrict__ dout, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int B, int D, int L,
-                                                           float* __restrict__ dx0, float* __restrict__ partials) {
+// Backward of the cross network.  A wave walks samples; element n lives in lane n % 64 throughout.  Parameter
+// gradients accumulate in lane-private LDS words of the wave's own region, x_l is recomputed from x0 and S where it
+// is needed, and the waves of a workgroup are summed in fixed order into one partial row:
+// partials[g] = [dW (L*D) | dB (L*D)], summed over g by the caller in fixed order.
+__global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ S,
+                                                            const float* __restrict__ dout, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int D, int L,
+                                                            float* __restrict__ dx0, float* __restrict__ partials) {
     extern __shared__ float sm[];
-    const int lane = threadIdx.x;
-    float* xl = sm;                   // [L][D]  x_l, l = 0..L-1
-    float* accW = xl + L * D;         // [L][D]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int region = (2 * L + 2) * D;
+    float* accW = sm + wv * region;   // [L][D]
     float* accB = accW + L * D;       // [L][D]
     float* dx = accB + L * D;         // [D]
     float* d0 = dx + D;               // [D]
     for (int i = lane; i < 2 * L * D; i += 64) accW[i] = 0.f;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int b = blockIdx.x * nw + wv; b < B; b += gridDim.x * nw) {
         const float* xs = x0 + (long long)b * D;
         const float* sb = S + (long long)b * L;
+        float part = 0.f;
         for (int n = lane; n < D; n += 64) {
-            float x = xs[n];
-            const float x0n = x;
-            for (int l = 0; l < L; ++l) {
-                xl[l * D + n] = x;
-                x = x0n * sb[l] + bias[l * D + n] + x;
-            }
-            dx[n] = dout[(long long)b * D + n];
+            const float g = dout[(long long)b * D + n];
+            dx[n] = g;
             d0[n] = 0.f;
+            part = fmaf(g, xs[n], part);
         }
         for (int l = L - 1; l >= 0; --l) {
-            float part = 0.f;
-            for (int n = lane; n < D; n += 64) part = fmaf(dx[n], xs[n], part);
             const float ds = rs_wave_sum(part);
             const float s = sb[l];
+            part = 0.f;
             for (int n = lane; n < D; n += 64) {
+                const float x0n = xs[n];
+                float xl = x0n;
+                for (int t = 0; t < l; ++t) xl = x0n * sb[t] + bias[t * D + n] + xl;
                 const float g = dx[n];
                 accB[l * D + n] += g;
-                accW[l * D + n] = fmaf(ds, xl[l * D + n], accW[l * D + n]);
+                accW[l * D + n] = fmaf(ds, xl, accW[l * D + n]);
                 d0[n] = fmaf(g, s, d0[n]);
-                dx[n] = fmaf(ds, w[l * D + n], g);
+                const float gn = fmaf(ds, w[l * D + n], g);
+                dx[n] = gn;
+                part = fmaf(gn, x0n, part);
             }
         }
         for (int n = lane; n < D; n += 64) dx0[(long long)b * D + n] = d0[n] + dx[n];
     }
+    __syncthreads();
     float* prow = partials + (long long)blockIdx.x * 2 * L * D;
-    for (int i = lane; i < 2 * L * D; i += 64) prow[i] = accW[i];
+    for (int i = threadIdx.x; i < 2 * L * D; i += blockDim.x) {
+        float t = 0.f;
+        for (int v = 0; v < nw; ++v) t += sm[v * region + i];
+        prow[i] = t;
+    }
 }
 
 // ---- NFM bi-interaction in the reference's form (model/NFM/NFM.py:42-44) ---------------------------
 // out[b,c] = 0.5 * ((sum_n e_n v_nc)^2 - sum_n e_n^2 v_nc^2), e = flattened (B, D) embeddings, v (D, K).
 constexpr int NFM_KMAX = 16;
+template <int KT>
 __global__ __launch_bounds__(256) void nfm_bi_fwd_kernel(const float* __restrict__ E, const float* __restrict__ V, int B,
                                                          int D, int K, float* __restrict__ out, float* __restrict__ s_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    float s[NFM_KMAX], q[NFM_KMAX];
+    float s[KT], q[KT];
 #pragma unroll
-    for (int c = 0; c < NFM_KMAX; ++c) s[c] = q[c] = 0.f;
+    for (int c = 0; c < KT; ++c) s[c] = q[c] = 0.f;
     for (int n = lane; n < D; n += 64) {
         const float e = E[(long long)b * D + n];
 #pragma unroll
-        for (int c = 0; c < NFM_KMAX; ++c) {
+        for (int c = 0; c < KT; ++c) {
             if (c < K) {
                 const float v = V[n * K + c];
                 s[c] = fmaf(e, v, s[c]);
@@ -277,7 +389,7 @@ __global__ __launch_bounds__(256) void nfm_bi_fwd_kernel(const float* __restrict
         }
     }
 #pragma unroll
-    for (int c = 0; c < NFM_KMAX; ++c) {
+    for (int c = 0; c < KT; ++c) {
         if (c < K) {
             const float sc = rs_wave_sum(s[c]), qc = rs_wave_sum(q[c]);
             if (lane == 0) {
@@ -289,20 +401,22 @@ __global__ __launch_bounds__(256) void nfm_bi_fwd_kernel(const float* __restrict
 }
 
 // dE[b,n] = sum_c g_bc (s_bc v_nc - e_bn v_nc^2);  dV[n,c] = sum_b g_bc e_bn (s_bc - e_bn v_nc)
-// (dV as per-workgroup partial rows, like the cross network's parameter gradients).
-__global__ __launch_bounds__(64) void nfm_bi_bwd_kernel(const float* __restrict__ E, const float* __restrict__ V,
-                                                        const float* __restrict__ s_in, const float* __restrict__ dout,
-                                                        int B, int D, int K, float* __restrict__ dE,
-                                                        float* __restrict__ partials) {
+// dV accumulates in lane-private LDS words per wave; the waves of a workgroup are summed in fixed order into
+// one partial row, like the cross network's parameter gradients.
+template <int KT>
+__global__ __launch_bounds__(256) void nfm_bi_bwd_kernel(const float* __restrict__ E, const float* __restrict__ V,
+                                                         const float* __restrict__ s_in, const float* __restrict__ dout,
+                                                         int B, int D, int K, float* __restrict__ dE,
+                                                         float* __restrict__ partials) {
     extern __shared__ float sm[];
-    const int lane = threadIdx.x;
-    float* acc = sm;                  // [D][K], row n private to lane n % 64
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float* acc = sm + wv * D * K;     // [D][K], row n private to lane n % 64
     for (int i = lane; i < D; i += 64)
         for (int c = 0; c < K; ++c) acc[i * K + c] = 0.f;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        float g[NFM_KMAX], s[NFM_KMAX];
+    for (int b = blockIdx.x * nw + wv; b < B; b += gridDim.x * nw) {
+        float g[KT], s[KT];
 #pragma unroll
-        for (int c = 0; c < NFM_KMAX; ++c) {
+        for (int c = 0; c < KT; ++c) {
             g[c] = c < K ? dout[(long long)b * K + c] : 0.f;
             s[c] = c < K ? s_in[(long long)b * K + c] : 0.f;
         }
@@ -310,7 +424,7 @@ __global__ __launch_bounds__(64) void nfm_bi_bwd_kernel(const float* __restrict_
             const float e = E[(long long)b * D + n];
             float de = 0.f;
 #pragma unroll
-            for (int c = 0; c < NFM_KMAX; ++c) {
+            for (int c = 0; c < KT; ++c) {
                 if (c < K) {
                     const float v = V[n * K + c];
                     de = fmaf(g[c], s[c] * v - e * v * v, de);
@@ -320,9 +434,13 @@ __global__ __launch_bounds__(64) void nfm_bi_bwd_kernel(const float* __restrict_
             dE[(long long)b * D + n] = de;
         }
     }
+    __syncthreads();
     float* prow = partials + (long long)blockIdx.x * D * K;
-    for (int i = lane; i < D; i += 64)
-        for (int c = 0; c < K; ++c) prow[i * K + c] = acc[i * K + c];
+    for (int i = threadIdx.x; i < D * K; i += blockDim.x) {
+        float t = 0.f;
+        for (int v = 0; v < nw; ++v) t += sm[v * D * K + i];
+        prow[i] = t;
+    }
 }
 
 // ---- AFM attention pooling (model/AFM/AFM.py:19-24, 36-42, 47-56) ----------------------------------
@@ -549,6 +667,234 @@ __global__ __launch_bounds__(64) void afm_bwd_kernel(const float* __restrict__ e
 }
 
 
+// Wave-per-sample form of the two AFM kernels above for F <= 64 fields.  Lane j owns field j (its embedding stays
+// in registers); in round t = 1..F/2 it meets partner (j + t) mod F, so every unordered pair is visited exactly
+// once (for even F the last round is taken by the lanes j < F/2 only) and every field is the partner of exactly
+// one lane per round.  That makes the backward deterministic without atomics: what a pair contributes to its
+// partner's gradient travels there by one cross-lane read per round.  Partner rows are read from an LDS copy of
+// the sample with row stride D+1 (conflict-free); the attention parameters are wave-uniform and come through the
+// scalar data path.  Work per pair is ~2*A*D FMAs forward and ~6*A*D backward: these kernels are bound by the
+// vector ALUs, not by HBM.
+__device__ __forceinline__ bool afm_active(int j, int t, int F) { return j < F && (2 * t != F || 2 * j < F); }
+
+template <int D>
+__device__ __forceinline__ void afm_load_row(const float* __restrict__ src, bool valid, float* ej) {
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = reinterpret_cast<const float4*>(src)[c];
+        ej[4 * c] = v.x; ej[4 * c + 1] = v.y; ej[4 * c + 2] = v.z; ej[4 * c + 3] = v.w;
+    }
+}
+
+// Scores of the lane's pairs: s -> sc[t-1][lane] (-inf where the lane has no pair in round t), pw . p -> gr[t-1][lane];
+// returns the lane's maximum score.
+template <int D, int A>
+__device__ __forceinline__ float afm_score_pass(const float* ej, const float* e, float* sc, float* gr, int lane, int F,
+                                                const float* __restrict__ W, const float* __restrict__ bA,
+                                                const float* __restrict__ h, const float* __restrict__ pw) {
+    constexpr int ES = D + 1;
+    const int T = F / 2;
+    float m = -INFINITY;
+    for (int t = 1; t <= T; ++t) {
+        int pr = lane + t;
+        if (pr >= F) pr -= F;
+        float s = -INFINITY, gsum = 0.f;
+        if (lane < F) {
+            float z[A];
+#pragma unroll
+            for (int a = 0; a < A; ++a) z[a] = bA[a];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float pk = ej[k] * e[pr * ES + k];
+                gsum = fmaf(pw[k], pk, gsum);
+#pragma unroll
+                for (int a = 0; a < A; ++a) z[a] = fmaf(W[a * D + k], pk, z[a]);
+            }
+            if (afm_active(lane, t, F)) {
+                s = 0.f;
+#pragma unroll
+                for (int a = 0; a < A; ++a) s = fmaf(h[a], fmaxf(z[a], 0.f), s);
+            }
+        }
+        sc[(t - 1) * 64 + lane] = s;
+        gr[(t - 1) * 64 + lane] = gsum;
+        m = fmaxf(m, s);
+    }
+    return m;
+}
+
+template <int D, int A>
+__global__ __launch_bounds__(256) void afm_fwd_wave_kernel(const float* __restrict__ emb, int B, int F,
+                                                           const float* __restrict__ W, const float* __restrict__ bA,
+                                                           const float* __restrict__ h, const float* __restrict__ pw,
+                                                           const float* __restrict__ pb, float* __restrict__ out,
+                                                           int region) {
+    extern __shared__ float sm[];
+    constexpr int ES = D + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int T = F / 2;
+    float* e = sm + wv * region;
+    float* sc = e + F * ES;
+    float* gr = sc + T * 64;
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        float ej[D];
+        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float m = afm_score_pass<D, A>(ej, e, sc, gr, lane, F, W, bA, h, pw);
+        m = wave_max(m);
+        float sum = 0.f, o = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float ex = expf(sc[t * 64 + lane] - m);
+            sum += ex;
+            o = fmaf(ex, gr[t * 64 + lane], o);
+        }
+        sum = rs_wave_sum(sum);
+        o = rs_wave_sum(o);
+        if (lane == 0) out[b] = o / sum + pb[0];
+    }
+}
+
+template <int D, int A>
+__global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                           int B, int F, const float* __restrict__ W,
+                                                           const float* __restrict__ bA, const float* __restrict__ h,
+                                                           const float* __restrict__ pw, float* __restrict__ demb,
+                                                           float* __restrict__ partials, int region) {
+    extern __shared__ float sm[];
+    constexpr int ES = D + 1;
+    constexpr int NP = A * D + 2 * A + D + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int T = F / 2;
+    float* e = sm + wv * region;
+    float* sc = e + F * ES;
+    float* gr = sc + T * 64;
+    float accW[A * D], accb[A], acch[A], accpw[D], accpb = 0.f;
+#pragma unroll
+    for (int i = 0; i < A * D; ++i) accW[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) accb[i] = acch[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) accpw[i] = 0.f;
+
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        float ej[D];
+        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float go = dout[b];
+        float m = afm_score_pass<D, A>(ej, e, sc, gr, lane, F, W, bA, h, pw);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float ex = expf(sc[t * 64 + lane] - m);
+            sc[t * 64 + lane] = ex;
+            sum += ex;
+        }
+        const float inv = 1.f / rs_wave_sum(sum);
+        float gbar = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float a = sc[t * 64 + lane] * inv;
+            const float g = go * gr[t * 64 + lane];
+            sc[t * 64 + lane] = a;
+            gr[t * 64 + lane] = g;
+            gbar = fmaf(a, g, gbar);
+        }
+        gbar = rs_wave_sum(gbar);
+        if (lane == 0) accpb += go;
+
+        float de[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) de[k] = 0.f;
+        for (int t = 1; t <= T; ++t) {
+            int pr = lane + t;
+            if (pr >= F) pr -= F;
+            int src = lane - t;
+            if (src < 0) src += F;
+            const float a = sc[(t - 1) * 64 + lane];               // 0 where the lane has no pair in this round
+            const float ds = a * (gr[(t - 1) * 64 + lane] - gbar);
+            float send[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) send[k] = 0.f;
+            if (lane < F) {
+                float ep[D], pk[D], z[A], dp[D];
+#pragma unroll
+                for (int a_ = 0; a_ < A; ++a_) z[a_] = bA[a_];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    ep[k] = e[pr * ES + k];
+                    pk[k] = ej[k] * ep[k];
+                    dp[k] = a * go * pw[k];
+                    accpw[k] = fmaf(go * a, pk[k], accpw[k]);
+#pragma unroll
+                    for (int a_ = 0; a_ < A; ++a_) z[a_] = fmaf(W[a_ * D + k], pk[k], z[a_]);
+                }
+#pragma unroll
+                for (int a_ = 0; a_ < A; ++a_) {
+                    const bool on = z[a_] > 0.f;
+                    const float dz = on ? ds * h[a_] : 0.f;
+                    accb[a_] += dz;
+                    acch[a_] = fmaf(ds, on ? z[a_] : 0.f, acch[a_]);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        dp[k] = fmaf(dz, W[a_ * D + k], dp[k]);
+                        accW[a_ * D + k] = fmaf(dz, pk[k], accW[a_ * D + k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    de[k] = fmaf(dp[k], ep[k], de[k]);
+                    send[k] = dp[k] * ej[k];
+                }
+            }
+            const bool take = lane < F && afm_active(src, t, F);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float r = __shfl(send[k], src, 64);
+                if (take) de[k] += r;
+            }
+        }
+        if (lane < F) {
+            float4* dst = reinterpret_cast<float4*>(demb + ((long long)b * F + lane) * D);
+#pragma unroll
+            for (int c = 0; c < D / 4; ++c) dst[c] = make_float4(de[4 * c], de[4 * c + 1], de[4 * c + 2], de[4 * c + 3]);
+        }
+    }
+    // lane partials -> wave sums (fixed shuffle order) -> one row per workgroup (waves added in fixed order)
+    __builtin_amdgcn_wave_barrier();
+    float* red = sm + wv * region;
+#pragma unroll
+    for (int i = 0; i < A * D; ++i) {
+        const float t = rs_wave_sum(accW[i]);
+        if (lane == 0) red[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float tb = rs_wave_sum(accb[i]), th = rs_wave_sum(acch[i]);
+        if (lane == 0) { red[A * D + i] = tb; red[A * D + A + i] = th; }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float t = rs_wave_sum(accpw[i]);
+        if (lane == 0) red[A * D + 2 * A + i] = t;
+    }
+    const float tpb = rs_wave_sum(accpb);
+    if (lane == 0) red[A * D + 2 * A + D] = tpb;
+    __syncthreads();
+    float* prow = partials + (long long)blockIdx.x * NP;
+    for (int i = threadIdx.x; i < NP; i += 256) prow[i] = ((sm[i] + sm[region + i]) + sm[2 * region + i]) + sm[3 * region + i];
+}
+
+
 // ---- FFM with true field-aware tables (model/FFM/FFM.py:43-62) -------------------------------------
 // Stacked table T [R, F*d]: row (row_offset[i] + x_i) holds the F vectors of feature value x_i, one per
 // partner field.  out[b] = sum_{i<j} < T[r_i][j], T[r_j][i] >.  One wave per sample, lanes over pairs: the
@@ -620,12 +966,54 @@ __global__ __launch_bounds__(256) void ffm_bwd_kernel(PlanView pv, const int64_t
 }
 
 constexpr int LDS_LIMIT = 64 * 1024;
+constexpr size_t LDS_BIG = 128 * 1024;      // workgroups that ask for more than 64 KB raise the kernel's limit first
+
+// Waves per workgroup (4, 2 or 1) whose private LDS regions of per_wave bytes fit LDS_BIG.
+int waves_for(size_t per_wave) { return 4 * per_wave <= LDS_BIG ? 4 : (2 * per_wave <= LDS_BIG ? 2 : 1); }
+
+bool raise_lds(const void* kern) {
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BIG) == hipSuccess;
+}
 constexpr int PARTIAL_ROWS_MAX = 512;
 
 int flat_blocks(long long n) {
     long long b = (n + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
+
+// Shapes served by the matrix-core PNN kernels (anything else takes the LDS kernels).
+bool pnn_mfma_ok(int F, int d, const float* emb) {
+    return F <= 64 && (d == 4 || d == 8 || d == 16 || d == 32) && (reinterpret_cast<uintptr_t>(emb) & 15) == 0;
+}
+int pnn_mfma_grid(int B) { const int g = rs_cdiv(B, 4); return g > 2048 ? 2048 : g; }
+#define RS_PNN_CASE(K, NB, DD) case (NB) * 100 + (DD): K(NB, DD); break;
+#define RS_PNN_DISPATCH(K)                                                                         \
+    switch (rs_cdiv(F, 16) * 100 + d) {                                                            \
+        RS_PNN_CASE(K, 1, 4) RS_PNN_CASE(K, 1, 8) RS_PNN_CASE(K, 1, 16) RS_PNN_CASE(K, 1, 32)      \
+        RS_PNN_CASE(K, 2, 4) RS_PNN_CASE(K, 2, 8) RS_PNN_CASE(K, 2, 16) RS_PNN_CASE(K, 2, 32)      \
+        RS_PNN_CASE(K, 3, 4) RS_PNN_CASE(K, 3, 8) RS_PNN_CASE(K, 3, 16) RS_PNN_CASE(K, 3, 32)      \
+        RS_PNN_CASE(K, 4, 4) RS_PNN_CASE(K, 4, 8) RS_PNN_CASE(K, 4, 16) RS_PNN_CASE(K, 4, 32)      \
+        default: break;                                                                            \
+    }
+
+// (embedding_dim, attention_dim) instantiated for the wave-per-sample AFM kernels.
+bool afm_wave_shape(int d, int A) {
+    return (d == 4 || d == 8 || d == 16 || d == 32) && (A == 4 || A == 8 || A == 16) && A * d <= 256;
+}
+// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays; at least one parameter-gradient row.
+int afm_region_floats(int F, int d, int A) {
+    const int need = F * (d + 1) + 2 * (F / 2) * 64, np = A * d + 2 * A + d + 1;
+    return need > np ? need : np;
+}
+#define RS_AFM_CASE(K, DD, AA) case (DD) * 100 + (AA): K(DD, AA); break;
+#define RS_AFM_DISPATCH(K)                                                                         \
+    switch (d * 100 + A) {                                                                         \
+        RS_AFM_CASE(K, 4, 4) RS_AFM_CASE(K, 4, 8) RS_AFM_CASE(K, 4, 16)                            \
+        RS_AFM_CASE(K, 8, 4) RS_AFM_CASE(K, 8, 8) RS_AFM_CASE(K, 8, 16)                            \
+        RS_AFM_CASE(K, 16, 4) RS_AFM_CASE(K, 16, 8) RS_AFM_CASE(K, 16, 16)                         \
+        RS_AFM_CASE(K, 32, 4) RS_AFM_CASE(K, 32, 8)                                                \
+        default: break;                                                                            \
+    }
 
 }  // namespace
 
@@ -661,6 +1049,14 @@ int rs_pnn_inner_fwd(const float* emb, int B, int F, int d, float* out, hipStrea
     RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_inner_fwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && out, "rs_pnn_inner_fwd: null argument");
+    if (pnn_mfma_ok(F, d, emb)) {
+        const int grid = pnn_mfma_grid(B);
+#define RS_PNN_F(NB, DD) hipLaunchKernelGGL((pnn_inner_fwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), 0, stream, emb, B, F, out)
+        RS_PNN_DISPATCH(RS_PNN_F)
+#undef RS_PNN_F
+        RS_CHECK_LAUNCH("rs_pnn_inner_fwd");
+        return RS_OK;
+    }
     const size_t lds = (size_t)4 * F * d * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_inner_fwd: F*d=%d does not fit the LDS staging", F * d);
     hipLaunchKernelGGL(pnn_inner_fwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), lds, stream, emb, B, F, d, out);
@@ -672,6 +1068,14 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
     RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_inner_bwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && dout && demb, "rs_pnn_inner_bwd: null argument");
+    if (pnn_mfma_ok(F, d, emb)) {
+        const int grid = pnn_mfma_grid(B);
+#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), 0, stream, emb, dout, B, F, demb)
+        RS_PNN_DISPATCH(RS_PNN_B)
+#undef RS_PNN_B
+        RS_CHECK_LAUNCH("rs_pnn_inner_bwd");
+        return RS_OK;
+    }
     const size_t lds = (size_t)4 * (F * d + F * (F - 1) / 2) * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_inner_bwd: F=%d d=%d does not fit the LDS staging", F, d);
     hipLaunchKernelGGL(pnn_inner_bwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), lds, stream, emb, dout, B, F, d, demb);
@@ -727,9 +1131,12 @@ int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const f
     RS_CHECK_ARG(x0 && S && dout && w && bias && dx0 && partials, "rs_dcn_cross_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_dcn_cross_bwd: partials must have %d rows",
                  rs_interact_partial_rows(B));
-    const size_t lds = (size_t)(3 * L + 2) * D * sizeof(float);
-    RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_dcn_cross_bwd: L=%d D=%d does not fit the LDS staging", L, D);
-    hipLaunchKernelGGL(dcn_cross_bwd_kernel, dim3(rows), dim3(64), lds, stream, x0, S, dout, w, bias, B, D, L, dx0, partials);
+    const size_t per_wave = (size_t)(2 * L + 2) * D * sizeof(float);
+    RS_CHECK_ARG(per_wave <= LDS_BIG, "rs_dcn_cross_bwd: L=%d D=%d does not fit the LDS staging", L, D);
+    const int nw = waves_for(per_wave);
+    RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(dcn_cross_bwd_kernel)), "rs_dcn_cross_bwd: cannot raise the LDS limit");
+    hipLaunchKernelGGL(dcn_cross_bwd_kernel, dim3(rows), dim3(64 * nw), nw * per_wave, stream, x0, S, dout, w, bias, B, D, L,
+                       dx0, partials);
     RS_CHECK_LAUNCH("rs_dcn_cross_bwd");
     return RS_OK;
 }
@@ -740,7 +1147,9 @@ int rs_nfm_bi_fwd(const float* E, const float* V, int B, int D, int K, float* ou
     RS_CHECK_ARG(B >= 0 && D > 0 && K > 0 && K <= NFM_KMAX, "rs_nfm_bi_fwd: bad sizes (hidden_dim <= %d)", NFM_KMAX);
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(E && V && out, "rs_nfm_bi_fwd: null argument");
-    hipLaunchKernelGGL(nfm_bi_fwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), 0, stream, E, V, B, D, K, out, s_out);
+#define RS_NFM_F(KT) hipLaunchKernelGGL(nfm_bi_fwd_kernel<KT>, dim3(rs_cdiv(B, 4)), dim3(256), 0, stream, E, V, B, D, K, out, s_out)
+    if (K <= 1) RS_NFM_F(1); else if (K <= 2) RS_NFM_F(2); else if (K <= 4) RS_NFM_F(4); else if (K <= 8) RS_NFM_F(8); else RS_NFM_F(16);
+#undef RS_NFM_F
     RS_CHECK_LAUNCH("rs_nfm_bi_fwd");
     return RS_OK;
 }
@@ -752,9 +1161,17 @@ int rs_nfm_bi_bwd(const float* E, const float* V, const float* s, const float* d
     RS_CHECK_ARG(E && V && s && dout && dE && partials, "rs_nfm_bi_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_nfm_bi_bwd: partials must have %d rows",
                  rs_interact_partial_rows(B));
-    const size_t lds = (size_t)D * K * sizeof(float);
-    RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_nfm_bi_bwd: D*K=%d does not fit the LDS staging", D * K);
-    hipLaunchKernelGGL(nfm_bi_bwd_kernel, dim3(rows), dim3(64), lds, stream, E, V, s, dout, B, D, K, dE, partials);
+    const size_t per_wave = (size_t)D * K * sizeof(float);
+    RS_CHECK_ARG(per_wave <= LDS_BIG, "rs_nfm_bi_bwd: D*K=%d does not fit the LDS staging", D * K);
+    const int nw = waves_for(per_wave);
+#define RS_NFM_B(KT)                                                                                                   \
+    do {                                                                                                               \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(nfm_bi_bwd_kernel<KT>)), "rs_nfm_bi_bwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL(nfm_bi_bwd_kernel<KT>, dim3(rows), dim3(64 * nw), nw * per_wave, stream, E, V, s, dout, B, D, K, dE, \
+                           partials);                                                                                  \
+    } while (0)
+    if (K <= 1) RS_NFM_B(1); else if (K <= 2) RS_NFM_B(2); else if (K <= 4) RS_NFM_B(4); else if (K <= 8) RS_NFM_B(8); else RS_NFM_B(16);
+#undef RS_NFM_B
     RS_CHECK_LAUNCH("rs_nfm_bi_bwd");
     return RS_OK;
 }
@@ -766,6 +1183,17 @@ int rs_afm_fwd(const float* emb, int B, int F, int d, int A, const float* W, con
     RS_CHECK_ARG(B >= 0 && F > 1 && A > 0, "rs_afm_fwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && W && bA && h && pw && pb && out, "rs_afm_fwd: null argument");
+    if (F <= 64 && afm_wave_shape(d, A) && (reinterpret_cast<uintptr_t>(emb) & 15) == 0) {
+        const int region = afm_region_floats(F, d, A);
+        const int wgrid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
+#define RS_AFM_FW(DD, AA)                                                                                              \
+    hipLaunchKernelGGL((afm_fwd_wave_kernel<DD, AA>), dim3(wgrid), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, \
+                       B, F, W, bA, h, pw, pb, out, region)
+        RS_AFM_DISPATCH(RS_AFM_FW)
+#undef RS_AFM_FW
+        RS_CHECK_LAUNCH("rs_afm_fwd");
+        return RS_OK;
+    }
     const int P = F * (F - 1) / 2;
     const size_t lds = (size_t)(A * d + 2 * A + d + F * d + P) * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_afm_fwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);
@@ -790,6 +1218,16 @@ int rs_afm_bwd(const float* emb, const float* dout, int B, int F, int d, int A, 
     RS_CHECK_ARG(B > 0 && F > 1, "rs_afm_bwd: bad sizes");
     RS_CHECK_ARG(emb && dout && W && bA && h && pw && demb && partials, "rs_afm_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_afm_bwd: partials must have %d rows", rs_interact_partial_rows(B));
+    if (F <= 64 && afm_wave_shape(d, A) && ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(demb)) & 15) == 0) {
+        const int region = afm_region_floats(F, d, A);
+#define RS_AFM_BW(DD, AA)                                                                                              \
+    hipLaunchKernelGGL((afm_bwd_wave_kernel<DD, AA>), dim3(rows), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, \
+                       dout, B, F, W, bA, h, pw, demb, partials, region)
+        RS_AFM_DISPATCH(RS_AFM_BW)
+#undef RS_AFM_BW
+        RS_CHECK_LAUNCH("rs_afm_bwd");
+        return RS_OK;
+    }
     const int P = F * (F - 1) / 2;
     const size_t lds = (size_t)(A * d + 2 * A + d + F * d + 2 * P + 64 * (d + 1)) * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_afm_bwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);

@@ -1,0 +1,131 @@
+"""Roofline of each feature-interaction kernel at the Criteo_x1 shape (F=39, d=16), one JSON line per kernel.
+
+Run on the GPU box:  python tools/bench_interact.py [B ...]   (default batches 4096 and 16384)
+
+`achieved` = algorithmic bytes (HBM-bound kernels) or FLOPs (PNN products) of one launch / average launch
+duration.  The duration is measured with HIP events over a HIP-graph replay of `iters` back-to-back launches, so
+host launch latency is outside the measurement and the kernels run as they do inside a captured training step.
+Algorithmic bytes count every input read once and every output written once:
+
+    pnn_inner fwd   B*(D + P)*4                 bwd  B*(D + P + D)*4
+    pnn_outer fwd   B*(D + P*d*d)*4             bwd  B*(D + P*d*d + D)*4
+    dcn_cross fwd   B*(D + D)*4  (+ S)          bwd  B*(D + D + D)*4
+    nfm_bi    fwd   B*(D + k)*4                 bwd  B*(D + k + D)*4
+    afm       fwd   B*(D + 1)*4                 bwd  B*(D + 1 + D)*4
+    ffm       fwd   B*F*(8 + F*d*4) + B*4       bwd  fwd bytes + unique rows * F*d*4 written
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from recommendsystem_amd import ops
+
+HBM_PEAK = 8000.0       # GB/s
+F, d = 39, 16
+D, P = F * d, F * (F - 1) // 2
+
+
+def graph_time(fn, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e30
+    for _ in range(5):
+        a.record()
+        g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) * 1e3 / iters)
+    return best
+
+
+def report(name, B, us, byts, flops=None, note=""):
+    line = {"kernel": name, "batch": B, "avg_us": round(us, 2), "algorithmic_MB": round(byts / 1e6, 2),
+            "GB_per_s": round(byts / us / 1e3, 1), "frac_of_hbm_peak": round(byts / us / 1e3 / HBM_PEAK, 3)}
+    if flops:
+        line["GFLOP"] = round(flops / 1e9, 3)
+        line["TFLOP_per_s"] = round(flops / us / 1e6, 2)
+    if note:
+        line["note"] = note
+    print(json.dumps(line), flush=True)
+
+
+def run(B):
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(2021)
+    emb = (torch.randn(B, F, d, generator=g) * 0.1).to(dev)
+
+    out = ops.pnn_inner_fwd(emb)
+    dout = torch.randn_like(out)
+    report("pnn_inner_fwd", B, graph_time(lambda: ops.pnn_inner_fwd(emb)), B * (D + P) * 4, flops=2.0 * B * P * d)
+    report("pnn_inner_bwd", B, graph_time(lambda: ops.pnn_inner_bwd(emb, dout)), B * (2 * D + P) * 4, flops=4.0 * B * P * d)
+
+    Bo = min(B, 4096)          # the materialised outer product is 759 KB per sample
+    embo = emb[:Bo].contiguous()
+    out = ops.pnn_outer_fwd(embo)
+    dout = torch.randn_like(out)
+    report("pnn_outer_fwd", Bo, graph_time(lambda: ops.pnn_outer_fwd(embo), 5), Bo * (D + P * d * d) * 4)
+    report("pnn_outer_bwd", Bo, graph_time(lambda: ops.pnn_outer_bwd(embo, dout), 5), Bo * (2 * D + P * d * d) * 4)
+    del out, dout
+
+    x0 = emb.view(B, D)
+    w = (torch.randn(3, D, generator=g) * 0.05).to(dev)
+    b = (torch.randn(3, D, generator=g) * 0.05).to(dev)
+    xo, S = ops.dcn_cross_fwd(x0, w, b)
+    dxo = torch.randn_like(xo)
+    report("dcn_cross_fwd(L=3)", B, graph_time(lambda: ops.dcn_cross_fwd(x0, w, b)), B * 2 * D * 4 + S.numel() * 4)
+    report("dcn_cross_bwd(L=3)", B, graph_time(lambda: ops.dcn_cross_bwd(x0, S, dxo, w, b)), B * 3 * D * 4 + S.numel() * 4)
+
+    V = torch.randn(D, 4, generator=g).to(dev)
+    o, s = ops.nfm_bi_fwd(x0, V)
+    do = torch.randn_like(o)
+    report("nfm_bi_fwd(k=4)", B, graph_time(lambda: ops.nfm_bi_fwd(x0, V)), B * (D + 4) * 4)
+    report("nfm_bi_bwd(k=4)", B, graph_time(lambda: ops.nfm_bi_bwd(x0, V, s, do)), B * (2 * D + 8) * 4)
+
+    A = 8
+    W = (torch.randn(A, d, generator=g) * 0.3).to(dev)
+    bA = torch.zeros(A, device=dev)
+    h = (torch.randn(1, A, generator=g) * 0.3).to(dev)
+    pw = (torch.randn(1, d, generator=g) * 0.3).to(dev)
+    pb = torch.zeros(1, device=dev)
+    o = ops.afm_fwd(emb, W, bA, h, pw, pb)
+    do = torch.randn_like(o)
+    afm_flops = B * P * (d + 2 * d * A + 2 * A + 2 * d)
+    report("afm_fwd(A=8)", B, graph_time(lambda: ops.afm_fwd(emb, W, bA, h, pw, pb)), B * (D + 1) * 4, flops=afm_flops)
+    report("afm_bwd(A=8)", B, graph_time(lambda: ops.afm_bwd(emb, do, W, bA, h, pw)), B * (2 * D + 1) * 4, flops=3 * afm_flops)
+
+    # FFM on field-aware rows of F*d floats; vocabularies as in bench.py, capped so the tables stay a few GB
+    vocabs = [100] * 13 + [min(int(10 ** (1 + 5 * i / 25)), 200000) for i in range(26)]
+    layout = ops.FieldLayout(vocabs, dev)
+    T = torch.randn(layout.total_rows, F * d, device=dev) * 1e-2
+    u = torch.rand(F, B, generator=g)
+    idx = torch.stack([(1 + (u[i] ** 6) * (v - 1)).long().clamp(1, v - 1) for i, v in enumerate(vocabs)], 0).to(dev)
+    o = ops.ffm_fwd(idx, layout, T)
+    do = torch.randn_like(o)
+    fb = B * F * (8 + F * d * 4) + B * 4
+    report("ffm_fwd", B, graph_time(lambda: ops.ffm_fwd(idx, layout, T), 5), fb, note=f"{layout.total_rows} rows of {F * d} floats")
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
+    uniq = sum(int(torch.unique(idx[i]).numel()) for i in range(F))
+    try:
+        t = graph_time(lambda: ops.ffm_bwd(plan, idx, T, do), 3)
+        report("ffm_bwd (dense dT incl. zero fill)", B, t, fb + layout.total_rows * F * d * 4, note=f"{uniq} touched rows")
+    except Exception as e:                                   # allocation inside capture etc.
+        print(json.dumps({"kernel": "ffm_bwd", "error": str(e)[:200]}), flush=True)
+
+
+if __name__ == "__main__":
+    for B in ([int(a) for a in sys.argv[1:]] or [4096, 16384]):
+        run(B)
