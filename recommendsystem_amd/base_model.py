@@ -13,7 +13,8 @@ reference run on the HIP layers.  Differences, all deliberate:
 * ``fix_earlystop=False`` keeps the reference's comparison (BaseModel.py:176 treats a LOWER AUC as an
   improvement); pass True for the conventional direction;
 * ``use_fused_step()`` switches train_step to the fused engine (sparse touched-rows update, one HIP
-  graph per step) -- see engine.py.
+  graph per step) -- see engine.py; ``use_sparse_step()`` gives every model kind the touched-rows table update
+  (sparse_trainer.py).
 """
 from __future__ import annotations
 
@@ -146,6 +147,13 @@ class BaseModel(nn.Module):
         """Route train_step through the fused HIP engine (engine.FusedTrainer)."""
         from .engine import FusedTrainer
         self._engine = FusedTrainer(self, **kw)
+        return self._engine
+
+    def use_sparse_step(self, **kw):
+        """Route train_step through sparse_trainer.SparseTrainer: this model's own forward under autograd, table
+        rows updated only where the batch touches them (any model kind)."""
+        from .sparse_trainer import SparseTrainer
+        self._engine = SparseTrainer(self, **kw)
         return self._engine
 
     # ---- loops (BaseModel.py:98-173) ---------------------------------------------------------

@@ -933,6 +933,96 @@ __global__ __launch_bounds__(256) void ffm_fwd_kernel(const int64_t* __restrict_
     if (lane == 0) out[b] = acc;
 }
 
+// Vector form for d = 4*LP (LP a power of two <= 16): LP lanes share a pair and read its two d-vectors as
+// float4s, so every 4*d-byte block of a table row is fetched by one contiguous request; 64/LP pairs are in flight
+// per wave and step.  The (i, j) of every pair sit in an LDS table built once per workgroup.
+template <int LP>
+__global__ __launch_bounds__(256) void ffm_fwd_vec_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ row_offset,
+                                                          const int64_t* __restrict__ vocab, const float* __restrict__ T,
+                                                          int B, int F, float* __restrict__ out, int* __restrict__ err_flag) {
+    extern __shared__ float sm[];
+    constexpr int d = 4 * LP, PPW = 64 / LP;
+    const int P = F * (F - 1) / 2, Ppad = (P + 1) & ~1;
+    int* tab = reinterpret_cast<int*>(sm);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long* rows = reinterpret_cast<long long*>(tab + Ppad) + wv * F;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i, j;
+        pair_decode(p, F, &i, &j);
+        tab[p] = i | (j << 16);
+    }
+    __syncthreads();
+    const int sub = lane % LP, pl = lane / LP;
+    const long long fd = (long long)F * d;
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        __builtin_amdgcn_wave_barrier();
+        for (int f = lane; f < F; f += 64) {
+            long long x = idx[(long long)f * B + b];
+            if (x < 0 || x >= vocab[f]) { x = 0; if (err_flag) atomicOr(err_flag, 1); }
+            rows[f] = (row_offset[f] + x) * fd;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float acc = 0.f;
+#pragma unroll 4
+        for (int p0 = 0; p0 < P; p0 += PPW) {
+            const int p = p0 + pl;
+            if (p < P) {
+                const int ij = tab[p], i = ij & 0xffff, j = ij >> 16;
+                const float4 x = *reinterpret_cast<const float4*>(T + rows[i] + j * d + 4 * sub);
+                const float4 y = *reinterpret_cast<const float4*>(T + rows[j] + i * d + 4 * sub);
+                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+            }
+        }
+        acc = rs_wave_sum(acc);
+        if (lane == 0) out[b] = acc;
+    }
+}
+
+// Gradients of the distinct table rows of a batch, compact: rowgrad[f, s, :] (F*d floats) for segment s of field f
+// of the sorted batch (see sparse.hip), in the layout the touched-rows optimizer kernels read, plus one
+// sum-of-squares partial per workgroup for the global gradient norm.  A workgroup walks the row's samples in
+// ascending order (fixed summation order, no atomics):
+//   rowgrad[f, s, j*d + k] = sum_b dout[b] * T[r_j(b)][f*d + k]   (j != f; the own-field block stays zero).
+__global__ __launch_bounds__(256) void ffm_bwd_rows_kernel(PlanView pv, const int64_t* __restrict__ idx,
+                                                           const int64_t* __restrict__ row_offset,
+                                                           const int64_t* __restrict__ vocab, const float* __restrict__ T,
+                                                           const float* __restrict__ dout, int B, int F, int cap, int d,
+                                                           float* __restrict__ rowgrad, float* __restrict__ norm_partials) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const int nseg = pv.counts[f * 4 + 2];
+    const int* sfc = pv.seg_first_chunk + (long long)f * (cap + 1);
+    const int* cst = pv.chunk_start + (long long)f * (cap + 1);
+    const int* ssrc = pv.sorted_src + (long long)f * cap;
+    const int fdv = F * d / 4;
+    const long long fd = (long long)F * d;
+    float nsq = 0.f;
+    for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int beg = cst[sfc[s]], end = cst[sfc[s + 1]];
+        float* dst = rowgrad + ((long long)f * cap + s) * fd;
+        for (int c4 = threadIdx.x; c4 < fdv; c4 += 256) {
+            const int c = 4 * c4, j = c / d, k = c - j * d;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j != f) {
+                const long long V = vocab[j], ro = row_offset[j];
+                const int64_t* col = idx + (long long)j * B;
+                for (int q = beg; q < end; ++q) {
+                    const int b = ssrc[q] / F;
+                    long long x = col[b];
+                    if (x < 0 || x >= V) x = 0;
+                    const float g = dout[b];
+                    const float4 t = *reinterpret_cast<const float4*>(T + (ro + x) * fd + (long long)f * d + k);
+                    acc.x = fmaf(g, t.x, acc.x); acc.y = fmaf(g, t.y, acc.y); acc.z = fmaf(g, t.z, acc.z); acc.w = fmaf(g, t.w, acc.w);
+                }
+            }
+            *reinterpret_cast<float4*>(dst + c) = acc;
+            nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        }
+    }
+    const float tot = rs_block_sum<256>(nsq, red);
+    if (threadIdx.x == 0) norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
 // Dense gradient of the stacked FFM table.  One workgroup per distinct row (a segment of the sorted batch,
 // see sparse.hip): it walks the row's samples in ascending order and sums
 //   dT[r_i][j*d+k] += dout[b] * T[r_j(b)][i*d+k]   (j != i)
@@ -975,6 +1065,7 @@ bool raise_lds(const void* kern) {
     return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BIG) == hipSuccess;
 }
 constexpr int PARTIAL_ROWS_MAX = 512;
+constexpr int FFM_ROW_GROUPS = 1024;    // workgroups per field of rs_ffm_bwd_rows
 
 int flat_blocks(long long n) {
     long long b = (n + 255) / 256;
@@ -1262,6 +1353,25 @@ int rs_ffm_fwd(const int64_t* idx, const int64_t* row_offset, const int64_t* voc
     RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_ffm_fwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(idx && row_offset && vocab && T && out, "rs_ffm_fwd: null argument");
+    const int LP = d / 4;
+    if (d % 4 == 0 && LP <= 16 && (LP & (LP - 1)) == 0 && F < 32768 && (reinterpret_cast<uintptr_t>(T) & 15) == 0) {
+        const int P = F * (F - 1) / 2;
+        const size_t vlds = (size_t)((P + 1) & ~1) * sizeof(int) + (size_t)4 * F * sizeof(long long);
+        if (vlds <= LDS_LIMIT) {
+            const int grid = rs_cdiv(B, 4) < 4096 ? rs_cdiv(B, 4) : 4096;
+#define RS_FFM_F(L) hipLaunchKernelGGL(ffm_fwd_vec_kernel<L>, dim3(grid), dim3(256), vlds, stream, idx, row_offset, vocab, T, B, F, out, err_flag)
+            switch (LP) {
+                case 1: RS_FFM_F(1); break;
+                case 2: RS_FFM_F(2); break;
+                case 4: RS_FFM_F(4); break;
+                case 8: RS_FFM_F(8); break;
+                default: RS_FFM_F(16); break;
+            }
+#undef RS_FFM_F
+            RS_CHECK_LAUNCH("rs_ffm_fwd");
+            return RS_OK;
+        }
+    }
     const size_t lds = (size_t)4 * F * sizeof(long long);
     hipLaunchKernelGGL(ffm_fwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), lds, stream, idx, row_offset, vocab, T, B, F, d, out,
                        err_flag);
@@ -1278,6 +1388,28 @@ int rs_ffm_bwd(const int* plan, const int64_t* idx, const int64_t* row_offset, c
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     hipLaunchKernelGGL(ffm_bwd_kernel, dim3(B, F), dim3(256), 0, stream, pv, idx, row_offset, vocab, T, dout, B, F, cap, d, dT);
     RS_CHECK_LAUNCH("rs_ffm_bwd");
+    return RS_OK;
+}
+
+// Number of sum-of-squares partials rs_ffm_bwd_rows writes.
+int rs_ffm_bwd_num_partials(int F, int cap) { return F * (cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS); }
+
+// Compact gradients of the touched rows of the stacked FFM table: rowgrad [F, cap, F*d] (segment s of field f at
+// [f, s, :], the layout rs_sparse_update / rs_sparse_scatter_dense read with row width F*d) and
+// norm_partials [rs_ffm_bwd_num_partials(F, cap)].  plan as for rs_ffm_bwd.  d must be a multiple of 4.
+int rs_ffm_bwd_rows(const int* plan, const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* T,
+                    const float* dout, int B, int F, int cap, int d, float* rowgrad, float* norm_partials,
+                    hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && F > 1 && d > 0 && cap >= B, "rs_ffm_bwd_rows: bad sizes");
+    RS_CHECK_ARG(d % 4 == 0, "rs_ffm_bwd_rows: embedding_dim %d is not a multiple of 4", d);
+    RS_CHECK_ARG(plan && idx && row_offset && vocab && T && dout && rowgrad && norm_partials, "rs_ffm_bwd_rows: null argument");
+    RS_CHECK_ARG(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(rowgrad)) & 15) == 0,
+                 "rs_ffm_bwd_rows: table and rowgrad must be 16-byte aligned");
+    const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
+    const int groups = cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS;
+    hipLaunchKernelGGL(ffm_bwd_rows_kernel, dim3(groups, F), dim3(256), 0, stream, pv, idx, row_offset, vocab, T, dout, B, F,
+                       cap, d, rowgrad, norm_partials);
+    RS_CHECK_LAUNCH("rs_ffm_bwd_rows");
     return RS_OK;
 }
 

@@ -503,6 +503,13 @@ int lanes_for(int d, int* VEC, int* C) {
     return -1;
 }
 
+// The optimizer and scatter kernels work on one row per lane group of a 256-thread workgroup, so they take
+// rows of up to 1024 floats (field-aware FFM rows).
+int lanes_wide(int d, int* VEC, int* C) {
+    if (d % 4 == 0 && d / 4 <= 256) { *VEC = 4; *C = d / 4; return 0; }
+    return lanes_for(d, VEC, C);
+}
+
 // entries per wave window for embedding_dim d: the largest power of two L with L*C <= 64
 int window_for(int d) {
     int VEC, C;
@@ -619,7 +626,7 @@ static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, in
     a.seg_row = pv.seg_row;
     a.counts = pv.counts;
     a.F = F; a.cap = cap; a.d = d;
-    return lanes_for(d, VEC, &a.C);
+    return lanes_wide(d, VEC, &a.C);
 }
 
 // Optimizer step on the touched rows only.  opt: 0 SGD, 1 Adam, 2 AdamW, 3 Adagrad (state in m).

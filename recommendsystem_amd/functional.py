@@ -60,7 +60,37 @@ class _GatherFn(torch.autograd.Function):
         return (None, None, *grads)
 
 
+class TableCapture:
+    """``with TableCapture() as cap:`` -- inside, the table lookups of this package (embedding rows, the one-hot
+    LR sum, the FFM term) do not build dense table gradients.  Each returns a leaf tensor and is recorded as
+    dict(kind, holder, idx, out); after ``loss.backward()`` the ``out.grad`` of a record is exactly what the
+    touched-rows kernels consume (engine.SparseTrainer).  Dense parameters keep their normal autograd path."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        if TableCapture.active is not None:
+            raise RuntimeError("TableCapture is not re-entrant")
+        TableCapture.active = self
+        return self
+
+    def __exit__(self, *exc):
+        TableCapture.active = None
+        return False
+
+    def record(self, kind, holder, idx, out):
+        out.requires_grad_(True)
+        self.records.append({"kind": kind, "holder": holder, "idx": idx, "out": out})
+        return out
+
+
 def embedding_lookup(idx, holder, weights) -> torch.Tensor:
+    cap = TableCapture.active
+    if cap is not None:
+        return cap.record("emb", holder, idx, ops.gather_fwd(idx, holder.layout, holder.stacked_for(weights)))
     return _GatherFn.apply(idx, holder, *weights)
 
 
@@ -93,7 +123,25 @@ class _LRFn(torch.autograd.Function):
         return (None, None, dbias, *grads)
 
 
+class _BiasGradFn(torch.autograd.Function):
+    """Identity on x (which already contains the bias); routes the column sum of the gradient to the bias."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g, ops.colsum(g.view(-1, 1))
+
+
 def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
+    cap = TableCapture.active
+    if cap is not None:
+        stacked1 = holder.stacked_for(weights1)
+        raw = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias.detach(), want_emb=False, want_lr=True)["lr"]
+        return _BiasGradFn.apply(cap.record("lr", holder, idx, raw).view(-1, 1), bias)
     return _LRFn.apply(idx, holder, bias, *weights1)
 
 

@@ -208,4 +208,9 @@ class FieldAwareTables(nn.Module):
         """idx: columnar [F, B] int64 on the device -> (B, 1) second-order term."""
         if not idx.is_cuda:
             raise RSError("FieldAwareTables: the batch must be on the device")
+        from .functional import TableCapture
+        cap = TableCapture.active
+        if cap is not None:
+            T = self._tab.stacked_for(self._tab.weights())
+            return cap.record("ffm", self._tab, idx, ops.ffm_fwd(idx, self._tab.layout, T)).view(-1, 1)
         return _FFMFn.apply(idx, self._tab, *self._tab.weights())

@@ -748,6 +748,41 @@ def ffm_bwd(plan: "SparsePlan", idx: torch.Tensor, T: torch.Tensor, dout: torch.
     return dT
 
 
+class FFMPlan(SparsePlan):
+    """Sort plan of a batch plus the compact buffer of field-aware row gradients (rows of F*d floats)."""
+
+    def __init__(self, layout: FieldLayout, cap: int, d: int, device=None):
+        super().__init__(layout, cap, 1, with_lr=False, device=device)
+        if d % 4:
+            raise RSError(f"FFM touched-rows update: embedding_dim {d} is not a multiple of 4")
+        self.ffm_d = int(d)
+        self.width = self.F * self.ffm_d
+        if self.width > 1024:
+            raise RSError(f"FFM touched-rows update: rows of {self.width} floats exceed 1024")
+        dev = device or layout.device
+        self.rowgrad_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
+        self.n_partials_wide = _lib.lib().rs_ffm_bwd_num_partials(self.F, self.cap)
+
+    def rows(self, idx: torch.Tensor, T: torch.Tensor, dout: torch.Tensor, norm_partials: torch.Tensor):
+        """Sorts idx, then fills the compact row gradients and norm_partials[:n_partials_wide]."""
+        Fn, B = idx.shape
+        _chk(T, torch.float32, "T", (self.layout.total_rows, self.width))
+        _chk(dout, torch.float32, "dout", (B,))
+        if norm_partials.numel() < self.n_partials_wide:
+            raise RSError("FFM backward: norm_partials too small")
+        self.sort_columnar(idx)
+        call("rs_ffm_bwd_rows", ptr(self.plan), ptr(idx), ptr(self.layout.row_offset_t), ptr(self.layout.vocab_t), ptr(T),
+             ptr(dout), B, self.F, self.cap, self.ffm_d, ptr(self.rowgrad_wide), ptr(norm_partials), stream())
+
+    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None):
+        call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.width, OPT_CODES[opt], ptr(self.rowgrad_wide),
+             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal), stream())
+
+    def scatter_wide(self, dT: torch.Tensor):
+        call("rs_sparse_scatter_dense", ptr(self.plan), self.F, self.cap, self.width, ptr(self.rowgrad_wide), ptr(None),
+             ptr(dT), ptr(None), stream())
+
+
 def axpy(a: float, x: torch.Tensor, y: torch.Tensor):
     """y += a * x (flat)."""
     _chk(x, torch.float32, "x")

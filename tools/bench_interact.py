@@ -107,23 +107,36 @@ def run(B):
     report("afm_fwd(A=8)", B, graph_time(lambda: ops.afm_fwd(emb, W, bA, h, pw, pb)), B * (D + 1) * 4, flops=afm_flops)
     report("afm_bwd(A=8)", B, graph_time(lambda: ops.afm_bwd(emb, do, W, bA, h, pw)), B * (2 * D + 1) * 4, flops=3 * afm_flops)
 
-    # FFM on field-aware rows of F*d floats; vocabularies as in bench.py, capped so the tables stay a few GB
+    # FFM on field-aware rows of F*d floats; vocabularies as in bench.py, capped so the tables stay a few GB.
+    # Two index distributions: skewed (hot rows, most reads served by L2 / Infinity Cache) and uniform (nearly every
+    # row distinct: the HBM-bound case the algorithmic byte count describes).
     vocabs = [100] * 13 + [min(int(10 ** (1 + 5 * i / 25)), 200000) for i in range(26)]
     layout = ops.FieldLayout(vocabs, dev)
     T = torch.randn(layout.total_rows, F * d, device=dev) * 1e-2
-    u = torch.rand(F, B, generator=g)
-    idx = torch.stack([(1 + (u[i] ** 6) * (v - 1)).long().clamp(1, v - 1) for i, v in enumerate(vocabs)], 0).to(dev)
-    o = ops.ffm_fwd(idx, layout, T)
-    do = torch.randn_like(o)
-    fb = B * F * (8 + F * d * 4) + B * 4
-    report("ffm_fwd", B, graph_time(lambda: ops.ffm_fwd(idx, layout, T), 5), fb, note=f"{layout.total_rows} rows of {F * d} floats")
-    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
-    uniq = sum(int(torch.unique(idx[i]).numel()) for i in range(F))
-    try:
-        t = graph_time(lambda: ops.ffm_bwd(plan, idx, T, do), 3)
-        report("ffm_bwd (dense dT incl. zero fill)", B, t, fb + layout.total_rows * F * d * 4, note=f"{uniq} touched rows")
-    except Exception as e:                                   # allocation inside capture etc.
-        print(json.dumps({"kernel": "ffm_bwd", "error": str(e)[:200]}), flush=True)
+    mT, vT = torch.zeros_like(T), torch.zeros_like(T)
+    hyper = ops.make_hyper(dev, 1e-3)
+    scal = torch.tensor([0.0, 1.0], device=dev)
+    plan = ops.FFMPlan(layout, cap=B, d=d)
+    parts = torch.zeros(plan.n_partials_wide, device=dev)
+    for dist in ("skewed", "uniform"):
+        u = torch.rand(F, B, generator=g)
+        if dist == "skewed":
+            u = u ** 6
+        idx = torch.stack([(1 + u[i] * (v - 1)).long().clamp(1, v - 1) for i, v in enumerate(vocabs)], 0).to(dev)
+        o = ops.ffm_fwd(idx, layout, T)
+        do = torch.randn_like(o)
+        uniq = sum(int(torch.unique(idx[i]).numel()) for i in range(F))
+        fb = B * F * (8 + F * d * 4) + B * 4
+        note = f"{dist} indices, {uniq} distinct rows of {F * d} floats among {layout.total_rows}"
+        report("ffm_fwd", B, graph_time(lambda: ops.ffm_fwd(idx, layout, T), 5), fb, note=note)
+        report("ffm_bwd_rows (sort + touched-row gradients)", B, graph_time(lambda: plan.rows(idx, T, do, parts), 5),
+               fb + uniq * F * d * 4, note=note)
+        report("ffm touched-rows Adam", B, graph_time(lambda: plan.update_wide("Adam", hyper, scal, T, mT, vT), 5),
+               uniq * F * d * 4 * 7, note=note + "; reads g,w,m,v and writes w,m,v")
+    if B <= 4096:
+        sp = ops.SparsePlan(layout, cap=B, d=1, with_lr=False)
+        t = graph_time(lambda: ops.ffm_bwd(sp, idx, T, do), 3)
+        report("ffm_bwd dense dT incl. zero fill (autograd path)", B, t, fb + layout.total_rows * F * d * 4)
 
 
 if __name__ == "__main__":
