@@ -34,7 +34,12 @@ def parse():
     p.add_argument("--batch", type=int, default=4096, help="samples per GPU per step")
     p.add_argument("--dim", type=int, default=16)
     p.add_argument("--hidden", type=str, default="1024,512,256")
-    p.add_argument("--model", type=str, default="deepfm", choices=["deepfm", "fm", "lr", "dnn", "widedeep"])
+    p.add_argument("--model", type=str, default="deepfm",
+                   choices=["deepfm", "fm", "lr", "dnn", "widedeep", "ffm", "pnn", "pnn_inner", "dcn", "nfm", "afm"],
+                   help="deepfm is the headline; ffm..afm run through the generic touched-rows trainer")
+    p.add_argument("--fields", type=int, default=39, choices=[39, 26],
+                   help="39 = 13 small-vocabulary + 26 categorical fields; 26 = the categorical fields only")
+    p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
     p.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
@@ -62,7 +67,12 @@ def build(args, device):
     from recommendsystem_amd import data, models
     from recommendsystem_amd.base_model import random_all
     random_all(2021)
-    rec = data.criteo_x1_recorder(embedding_dim=args.dim, batch_size=args.batch)
+    vs = data.criteo_x1_vocab_sizes()
+    if args.fields == 26:
+        vs = vs[13:]
+    if args.model == "ffm":
+        vs = [min(v, 200000) for v in vs]       # field-aware rows are F*d floats: keep table + Adam moments in tens of GB
+    rec = data.criteo_x1_recorder(embedding_dim=args.dim, batch_size=args.batch, vocab_sizes=vs)
     hidden = [int(h) for h in args.hidden.split(",") if h]
     gpu = device.index
     kw = dict(optimizer_type=args.optimizer)
@@ -74,8 +84,19 @@ def build(args, device):
         m = models.LR(rec, 1e-3, gpu, **kw)
     elif args.model == "dnn":
         m = models.DNN(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
-    else:
+    elif args.model == "widedeep":
         m = models.WideDeep(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    elif args.model == "ffm":
+        m = models.FFM(rec, 1e-3, gpu, **kw)
+    elif args.model in ("pnn", "pnn_inner"):
+        m = models.PNN(rec, 1e-3, gpu, hidden_dim_list=hidden, pnn_type="both" if args.model == "pnn" else "inner",
+                       normalization=None, **kw)
+    elif args.model == "dcn":
+        m = models.DCN(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    elif args.model == "nfm":
+        m = models.NFM(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
+    else:
+        m = models.AFM(rec, 1e-3, gpu, **kw)
     m.train()
     return m, rec, hidden
 
@@ -84,10 +105,14 @@ def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
     """The CPU oracle's training step (oracle/ctr_oracle.py: per-field nn.Embedding, torch.stack,
     sum-square, nn.Linear stack, BCE, clip_grad_norm_, dense torch optimizer) on the same batches."""
     from oracle import ctr_oracle as O
-    cores = min(16, os.cpu_count() or 1)
+    cores = args.cpu_threads or min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     torch.manual_seed(2021)
-    m = O.OracleCTRModel(args.model, rec.feature_map, rec.features, args.dim, hidden=hidden, normalization=None)
+    okw = {"ffm": {}, "afm": {}, "pnn": {"pnn_type": "both"}, "pnn_inner": {"pnn_type": "inner"}}.get(
+        args.model, {"hidden": hidden, "normalization": None})
+    if args.model in ("pnn", "pnn_inner"):
+        okw.update(hidden=hidden, normalization=None)
+    m = O.OracleCTRModel(args.model.split("_")[0], rec.feature_map, rec.features, args.dim, **okw)
     m.train()
     opt = O.make_optimizer(args.optimizer, m.parameters(), 1e-3)
     cols = rec.features
@@ -142,8 +167,10 @@ def main():
     if use_dist:
         from recommendsystem_amd.dist import DistributedTrainer
         eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.dist_graph), stage_cpu=rehearse)
-    else:
+    elif getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep"):
         eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
+    else:
+        eng = model.use_sparse_step(use_graph=bool(args.graph))
 
     nb = max(1, args.distinct_batches)
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
@@ -239,7 +266,7 @@ def main():
     roofline = None
     if gemm_us > 0:
         ach = gemm_flop / gemm_us / 1e6
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all MLP GEMM launches of a step",
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_dma_kernel (v_mfma_f32_16x16x4_f32), all MLP GEMM launches of a step",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_flop_per_step": gemm_flop / args.steps, "us_per_step": round(gemm_us / args.steps, 1),
@@ -269,8 +296,10 @@ def main():
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} training step, Criteo_x1-shaped: 39 fields (13 small-vocab + 26 "
-                                   f"log-spaced 10..1e6), embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
+            "config": {"workload": f"{args.model} training step, Criteo_x1-shaped: "
+                                   + ("39 fields (13 small-vocab + 26 log-spaced 10..1e6)" if args.fields == 39
+                                      else "26 categorical fields (log-spaced 10..1e6)")
+                                   + f", embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
                        "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
                        "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",

@@ -179,11 +179,13 @@ int rs_ffm_bwd(const int* plan, const int64_t* idx, const int64_t* row_offset, c
 /* The same gradient for the touched rows only: rowgrad [F, cap, F*d] holds segment s of field f of the plan at
  * [f, s, :] -- the layout rs_sparse_update / rs_sparse_scatter_dense read when called with row width F*d (rows of up
  * to 1024 floats) -- and norm_partials [rs_ffm_bwd_num_partials(F, cap)] the sums of squares for the global-norm clip
- * (BaseModel.py:148).  Replaces the dense (V_f, F*d) gradient + dense optimizer sweep of FFM.py's tables. */
+ * (BaseModel.py:148).  chunk_part [F, cap, F*d] is scratch (partial sums of rows that span several chunks of the
+ * plan; the plan's window L must be <= 64).  Replaces the dense (V_f, F*d) gradient + dense optimizer sweep of
+ * FFM.py's tables. */
 int rs_ffm_bwd_num_partials(int F, int cap);
 int rs_ffm_bwd_rows(const int* plan, const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* T,
-                    const float* dout, int B, int F, int cap, int d, float* rowgrad, float* norm_partials,
-                    rs_stream_t stream);
+                    const float* dout, int B, int F, int cap, int d, float* rowgrad, float* chunk_part,
+                    float* norm_partials, rs_stream_t stream);
 
 /* ---- K3: deterministic sparse embedding backward + optimizer (BaseModel.py:141-150) ---------- */
 /* plan: int32 scratch of rs_sort_plan_ints(F, cap) elements.  Per field, `nsrc` sub-lists of keys are

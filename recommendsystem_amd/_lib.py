@@ -83,7 +83,7 @@ _SIGS = {
     "rs_afm_bwd": [c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, c_stream],
     "rs_ffm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, I, I, I, c_f32p, c_i32p, c_stream],
     "rs_ffm_bwd": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_stream],
-    "rs_ffm_bwd_rows": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_stream],
+    "rs_ffm_bwd_rows": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
 }
 # entry points that do not follow the "returns int status" convention: name -> (restype, argtypes)
 _PLAIN = {

@@ -979,45 +979,106 @@ __global__ __launch_bounds__(256) void ffm_fwd_vec_kernel(const int64_t* __restr
 }
 
 // Gradients of the distinct table rows of a batch, compact: rowgrad[f, s, :] (F*d floats) for segment s of field f
-// of the sorted batch (see sparse.hip), in the layout the touched-rows optimizer kernels read, plus one
-// sum-of-squares partial per workgroup for the global gradient norm.  A workgroup walks the row's samples in
-// ascending order (fixed summation order, no atomics):
+// of the sorted batch (see sparse.hip), in the layout the touched-rows optimizer kernels read, plus sum-of-squares
+// partials for the global gradient norm.
 //   rowgrad[f, s, j*d + k] = sum_b dout[b] * T[r_j(b)][f*d + k]   (j != f; the own-field block stays zero).
-__global__ __launch_bounds__(256) void ffm_bwd_rows_kernel(PlanView pv, const int64_t* __restrict__ idx,
-                                                           const int64_t* __restrict__ row_offset,
-                                                           const int64_t* __restrict__ vocab, const float* __restrict__ T,
-                                                           const float* __restrict__ dout, int B, int F, int cap, int d,
-                                                           float* __restrict__ rowgrad, float* __restrict__ norm_partials) {
+// Two phases, both in fixed summation order (no atomics).  Phase 1: one workgroup per chunk of the plan (at most
+// CH consecutive entries of one row; a hot row of a skewed batch spans many chunks, which proceed in parallel); the
+// sum goes straight to rowgrad when the row has a single chunk, else to chunk_part[f, chunk, :].  Phase 2 adds the
+// chunk sums of the multi-chunk rows in chunk order.
+constexpr int FFM_TILE = 64;         // >= entries per chunk of a plan built for 1-dim rows
+__global__ __launch_bounds__(256) void ffm_bwd_chunks_kernel(PlanView pv, const int64_t* __restrict__ idx,
+                                                             const int64_t* __restrict__ row_offset,
+                                                             const int64_t* __restrict__ vocab, const float* __restrict__ T,
+                                                             const float* __restrict__ dout, int B, int F, int cap, int d,
+                                                             float* __restrict__ rowgrad, float* __restrict__ chunk_part,
+                                                             float* __restrict__ norm_partials) {
+    __shared__ float red[4];
+    __shared__ int sb[FFM_TILE];     // samples of the chunk's entries
+    __shared__ float sg[FFM_TILE];   // their dL/dout
+    constexpr int U = 8;             // independent load chains in flight per thread
+    const int f = blockIdx.y;
+    const int nchunk = pv.counts[f * 4 + 1];
+    const int* sfc = pv.seg_first_chunk + (long long)f * (cap + 1);
+    const int* cst = pv.chunk_start + (long long)f * (cap + 1);
+    const int* ssrc = pv.sorted_src + (long long)f * cap;
+    const int* eseg = pv.entry_seg + (long long)f * cap;
+    const long long fd = (long long)F * d;
+    // one float4 of the row per thread (host side: F*d <= 1024)
+    const int c = 4 * threadIdx.x, j = c / d, k = c - j * d;
+    const bool has = c < F * d, live = has && j != f;
+    const long long V = live ? vocab[j] : 0, ro = live ? row_offset[j] : 0;
+    const int64_t* col = idx + (long long)(live ? j : 0) * B;
+    const float* Tf = T + (long long)f * d + k;
+    float nsq = 0.f;
+    for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const int beg = cst[ch], end = cst[ch + 1];
+        const int seg = eseg[beg];
+        const bool single = sfc[seg + 1] - sfc[seg] == 1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q0 = beg; q0 < end; q0 += FFM_TILE) {
+            const int n = end - q0 < FFM_TILE ? end - q0 : FFM_TILE;
+            __syncthreads();
+            if ((int)threadIdx.x < n) {
+                const int b = ssrc[q0 + threadIdx.x] / F;
+                sb[threadIdx.x] = b;
+                sg[threadIdx.x] = dout[b];
+            }
+            __syncthreads();
+            if (live) {
+                for (int t0 = 0; t0 < n; t0 += U) {
+                    long long x[U];
+                    float4 tv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int t = t0 + u < n ? t0 + u : n - 1;
+                        const long long xx = col[sb[t]];
+                        x[u] = (xx < 0 || xx >= V) ? 0 : xx;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) tv[u] = *reinterpret_cast<const float4*>(Tf + (ro + x[u]) * fd);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {                  // ascending entries: fixed summation order
+                        if (t0 + u < n) {
+                            const float g = sg[t0 + u];
+                            acc.x = fmaf(g, tv[u].x, acc.x); acc.y = fmaf(g, tv[u].y, acc.y);
+                            acc.z = fmaf(g, tv[u].z, acc.z); acc.w = fmaf(g, tv[u].w, acc.w);
+                        }
+                    }
+                }
+            }
+        }
+        if (has) {
+            float* dst = single ? rowgrad + ((long long)f * cap + seg) * fd : chunk_part + ((long long)f * cap + ch) * fd;
+            *reinterpret_cast<float4*>(dst + c) = acc;
+            if (single) nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        }
+    }
+    const float tot = rs_block_sum<256>(nsq, red);
+    if (threadIdx.x == 0) norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void ffm_bwd_finish_kernel(PlanView pv, int F, int cap, int d,
+                                                             float* __restrict__ rowgrad, const float* __restrict__ chunk_part,
+                                                             float* __restrict__ norm_partials) {
     __shared__ float red[4];
     const int f = blockIdx.y;
     const int nseg = pv.counts[f * 4 + 2];
     const int* sfc = pv.seg_first_chunk + (long long)f * (cap + 1);
-    const int* cst = pv.chunk_start + (long long)f * (cap + 1);
-    const int* ssrc = pv.sorted_src + (long long)f * cap;
-    const int fdv = F * d / 4;
     const long long fd = (long long)F * d;
+    const int c = 4 * threadIdx.x;
+    const bool has = c < F * d;
     float nsq = 0.f;
     for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
-        const int beg = cst[sfc[s]], end = cst[sfc[s + 1]];
-        float* dst = rowgrad + ((long long)f * cap + s) * fd;
-        for (int c4 = threadIdx.x; c4 < fdv; c4 += 256) {
-            const int c = 4 * c4, j = c / d, k = c - j * d;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j != f) {
-                const long long V = vocab[j], ro = row_offset[j];
-                const int64_t* col = idx + (long long)j * B;
-                for (int q = beg; q < end; ++q) {
-                    const int b = ssrc[q] / F;
-                    long long x = col[b];
-                    if (x < 0 || x >= V) x = 0;
-                    const float g = dout[b];
-                    const float4 t = *reinterpret_cast<const float4*>(T + (ro + x) * fd + (long long)f * d + k);
-                    acc.x = fmaf(g, t.x, acc.x); acc.y = fmaf(g, t.y, acc.y); acc.z = fmaf(g, t.z, acc.z); acc.w = fmaf(g, t.w, acc.w);
-                }
-            }
-            *reinterpret_cast<float4*>(dst + c) = acc;
-            nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        const int c0 = sfc[s], c1 = sfc[s + 1];
+        if (c1 - c0 < 2 || !has) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ch = c0; ch < c1; ++ch) {
+            const float4 t = *reinterpret_cast<const float4*>(chunk_part + ((long long)f * cap + ch) * fd + c);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
+        *reinterpret_cast<float4*>(rowgrad + ((long long)f * cap + s) * fd + c) = acc;
+        nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
     }
     const float tot = rs_block_sum<256>(nsq, red);
     if (threadIdx.x == 0) norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
@@ -1065,7 +1126,8 @@ bool raise_lds(const void* kern) {
     return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BIG) == hipSuccess;
 }
 constexpr int PARTIAL_ROWS_MAX = 512;
-constexpr int FFM_ROW_GROUPS = 1024;    // workgroups per field of rs_ffm_bwd_rows
+constexpr int FFM_ROW_GROUPS = 1024;   // workgroups per field of rs_ffm_bwd_rows, phase 1 (chunks)
+constexpr int FFM_FINISH_GROUPS = 64;  // phase 2 (rows with several chunks)
 
 int flat_blocks(long long n) {
     long long b = (n + 255) / 256;
@@ -1392,23 +1454,30 @@ int rs_ffm_bwd(const int* plan, const int64_t* idx, const int64_t* row_offset, c
 }
 
 // Number of sum-of-squares partials rs_ffm_bwd_rows writes.
-int rs_ffm_bwd_num_partials(int F, int cap) { return F * (cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS); }
+int rs_ffm_bwd_num_partials(int F, int cap) {
+    return F * ((cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS) + (cap < FFM_FINISH_GROUPS ? cap : FFM_FINISH_GROUPS));
+}
 
 // Compact gradients of the touched rows of the stacked FFM table: rowgrad [F, cap, F*d] (segment s of field f at
 // [f, s, :], the layout rs_sparse_update / rs_sparse_scatter_dense read with row width F*d) and
-// norm_partials [rs_ffm_bwd_num_partials(F, cap)].  plan as for rs_ffm_bwd.  d must be a multiple of 4.
+// norm_partials [rs_ffm_bwd_num_partials(F, cap)].  chunk_part [F, cap, F*d] is scratch.  plan: rs_sparse_bwd_sort of
+// the same columnar idx with capacity cap and window L <= 64.  d % 4 == 0 and F*d <= 1024.
 int rs_ffm_bwd_rows(const int* plan, const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* T,
-                    const float* dout, int B, int F, int cap, int d, float* rowgrad, float* norm_partials,
-                    hipStream_t stream) {
+                    const float* dout, int B, int F, int cap, int d, float* rowgrad, float* chunk_part,
+                    float* norm_partials, hipStream_t stream) {
     RS_CHECK_ARG(B > 0 && F > 1 && d > 0 && cap >= B, "rs_ffm_bwd_rows: bad sizes");
-    RS_CHECK_ARG(d % 4 == 0, "rs_ffm_bwd_rows: embedding_dim %d is not a multiple of 4", d);
-    RS_CHECK_ARG(plan && idx && row_offset && vocab && T && dout && rowgrad && norm_partials, "rs_ffm_bwd_rows: null argument");
-    RS_CHECK_ARG(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(rowgrad)) & 15) == 0,
-                 "rs_ffm_bwd_rows: table and rowgrad must be 16-byte aligned");
+    RS_CHECK_ARG(d % 4 == 0 && F * d <= 1024, "rs_ffm_bwd_rows: needs embedding_dim %% 4 == 0 and F*d <= 1024 (F=%d d=%d)", F, d);
+    RS_CHECK_ARG(plan && idx && row_offset && vocab && T && dout && rowgrad && chunk_part && norm_partials,
+                 "rs_ffm_bwd_rows: null argument");
+    RS_CHECK_ARG(((reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(rowgrad) |
+                   reinterpret_cast<uintptr_t>(chunk_part)) & 15) == 0,
+                 "rs_ffm_bwd_rows: table, rowgrad and chunk_part must be 16-byte aligned");
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
-    const int groups = cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS;
-    hipLaunchKernelGGL(ffm_bwd_rows_kernel, dim3(groups, F), dim3(256), 0, stream, pv, idx, row_offset, vocab, T, dout, B, F,
-                       cap, d, rowgrad, norm_partials);
+    const int g1 = cap < FFM_ROW_GROUPS ? cap : FFM_ROW_GROUPS, g2 = cap < FFM_FINISH_GROUPS ? cap : FFM_FINISH_GROUPS;
+    hipLaunchKernelGGL(ffm_bwd_chunks_kernel, dim3(g1, F), dim3(256), 0, stream, pv, idx, row_offset, vocab, T, dout, B, F,
+                       cap, d, rowgrad, chunk_part, norm_partials);
+    hipLaunchKernelGGL(ffm_bwd_finish_kernel, dim3(g2, F), dim3(256), 0, stream, pv, F, cap, d, rowgrad, chunk_part,
+                       norm_partials + (size_t)F * g1);
     RS_CHECK_LAUNCH("rs_ffm_bwd_rows");
     return RS_OK;
 }

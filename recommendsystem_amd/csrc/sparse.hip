@@ -448,13 +448,25 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
+// Sum of n partials over a 1024-thread block: four independent load/add chains per thread, combined in a fixed
+// order (deterministic); result valid in every thread.
+__device__ __forceinline__ float sum_partials_1024(const float* __restrict__ partials, int n, float* red /* 16 floats */) {
+    constexpr int NT = 1024;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 3 * NT < n; i += 4 * NT) {
+        const float a = partials[i], b = partials[i + NT], c = partials[i + 2 * NT], d = partials[i + 3 * NT];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; i < n; i += NT) s0 += partials[i];
+    return rs_block_sum<NT>((s0 + s1) + (s2 + s3), red);
+}
+
 // total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6))   [torch clip_grad_norm_]
-__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partials, int n, float max_norm,
-                                                        float* __restrict__ scal) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
-    const float tot = rs_block_sum<256>(s, red);
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ partials, int n, float max_norm,
+                                                         float* __restrict__ scal) {
+    __shared__ float red[16];
+    const float tot = sum_partials_1024(partials, n, red);
     if (threadIdx.x == 0) {
         const float nrm = sqrtf(tot);
         scal[0] = nrm;
@@ -476,12 +488,10 @@ __global__ void opt_prepare_kernel(long long* step, float* hyper) {
 }
 
 // clip_coef_kernel and opt_prepare_kernel in one launch
-__global__ __launch_bounds__(256) void clip_prepare_kernel(const float* __restrict__ partials, int n, float max_norm,
-                                                           float* __restrict__ scal, long long* step, float* hyper) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
-    const float tot = rs_block_sum<256>(s, red);
+__global__ __launch_bounds__(1024) void clip_prepare_kernel(const float* __restrict__ partials, int n, float max_norm,
+                                                            float* __restrict__ scal, long long* step, float* hyper) {
+    __shared__ float red[16];
+    const float tot = sum_partials_1024(partials, n, red);
     if (threadIdx.x == 0) {
         const float nrm = sqrtf(tot);
         scal[0] = nrm;
@@ -698,7 +708,7 @@ int rs_sumsq_partials(const float* x, long long n, float* partials, int nblocks,
 // (nn.utils.clip_grad_norm_ as called at model/utils/BaseModel.py:148); max_norm <= 0 disables.
 int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, hipStream_t stream) {
     RS_CHECK_ARG(partials && scal && n >= 0, "rs_clip_coef: bad arguments");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, partials, n, max_norm, scal);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, stream, partials, n, max_norm, scal);
     RS_CHECK_LAUNCH("rs_clip_coef");
     return RS_OK;
 }
@@ -707,7 +717,7 @@ int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, hipS
 int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
                         hipStream_t stream) {
     RS_CHECK_ARG(partials && scal && step && hyper && n >= 0, "rs_clip_and_prepare: bad arguments");
-    hipLaunchKernelGGL(clip_prepare_kernel, dim3(1), dim3(256), 0, stream, partials, n, max_norm, scal, step, hyper);
+    hipLaunchKernelGGL(clip_prepare_kernel, dim3(1), dim3(1024), 0, stream, partials, n, max_norm, scal, step, hyper);
     RS_CHECK_LAUNCH("rs_clip_and_prepare");
     return RS_OK;
 }

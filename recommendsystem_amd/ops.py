@@ -760,7 +760,10 @@ class FFMPlan(SparsePlan):
         if self.width > 1024:
             raise RSError(f"FFM touched-rows update: rows of {self.width} floats exceed 1024")
         dev = device or layout.device
+        if self.CHUNK > 64:
+            raise RSError("FFM touched-rows update: plan window exceeds 64 entries")
         self.rowgrad_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
+        self.chunk_part_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
         self.n_partials_wide = _lib.lib().rs_ffm_bwd_num_partials(self.F, self.cap)
 
     def rows(self, idx: torch.Tensor, T: torch.Tensor, dout: torch.Tensor, norm_partials: torch.Tensor):
@@ -772,7 +775,8 @@ class FFMPlan(SparsePlan):
             raise RSError("FFM backward: norm_partials too small")
         self.sort_columnar(idx)
         call("rs_ffm_bwd_rows", ptr(self.plan), ptr(idx), ptr(self.layout.row_offset_t), ptr(self.layout.vocab_t), ptr(T),
-             ptr(dout), B, self.F, self.cap, self.ffm_d, ptr(self.rowgrad_wide), ptr(norm_partials), stream())
+             ptr(dout), B, self.F, self.cap, self.ffm_d, ptr(self.rowgrad_wide), ptr(self.chunk_part_wide), ptr(norm_partials),
+             stream())
 
     def update_wide(self, opt: str, hyper, scal, T, m=None, v=None):
         call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.width, OPT_CODES[opt], ptr(self.rowgrad_wide),

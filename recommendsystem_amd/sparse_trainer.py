@@ -18,6 +18,9 @@ them, and a dense optimizer sweep over every row each step (torch.optim on nn.Em
 
 Semantics: identical to the reference's dense optimizers for SGD and Adagrad; Adam/AdamW are the "lazy" variant
 (rows a batch does not touch keep weights and moments).  ``emb_regular`` (a gradient on every row) is not supported.
+
+``use_graph=True`` replays the whole step, autograd backward included, from a HIP graph (one per batch shape), which
+removes the host cost of the ~60 launches and of the autograd bookkeeping.
 """
 from __future__ import annotations
 
@@ -34,8 +37,12 @@ N_DENSE_PARTIALS = 256
 
 
 class SparseTrainer:
-    def __init__(self, model, max_norm: float = 10.0, optimizer_type=None, lr=None):
+    def __init__(self, model, max_norm: float = 10.0, optimizer_type=None, lr=None, use_graph: bool = False):
         self.model = model
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._graph_pool = None
+        self._capture_stream = None
         self.max_norm = float(max_norm)
         self.opt = optimizer_type or model.optimizer_type
         if self.opt not in ops.OPT_CODES:
@@ -111,11 +118,90 @@ class SparseTrainer:
             self._plans[key] = p
         return p
 
+    def step_tensors(self, idx: torch.Tensor, labels: torch.Tensor, resident: bool = False) -> torch.Tensor:
+        """One step on a device-resident columnar batch (idx [F, B] int64 in the embedding layer's column order,
+        labels [B]), the calling convention of the fused engine.  With use_graph the whole step -- forward, autograd
+        backward, touched-rows reduction, optimizer -- is replayed from a HIP graph; resident=True promises that these
+        exact tensors stay alive and are re-used (one graph per buffer pair, no copies), otherwise the batch is copied
+        into the graph's static input buffers first."""
+        if not self.use_graph:
+            return self._step_impl(self._columns(idx), labels)
+        if resident:
+            key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
+            ent = self._graphs.get(key)
+            if ent is None:
+                ent = self._graphs[key] = self._capture(idx, labels)
+        else:
+            key = ("static", tuple(idx.shape), labels.dtype)
+            ent = self._graphs.get(key)
+            if ent is None:
+                ent = self._graphs[key] = self._capture(idx.clone(), labels.clone())
+            ent["idx"].copy_(idx)
+            ent["labels"].copy_(labels)
+        ent["graph"].replay()
+        return ent["loss"]
+
+    def _columns(self, idx):
+        return {c: idx[i] for i, c in enumerate(self.model.embedding_layer.lookup_columns)}
+
+    def _mutable_state(self):
+        ts = [self.flat_w, self.step_count, self.hyper, self.scal]
+        ts += [x for x in (self.flat_m, self.flat_v) if x is not None]
+        dense = {id(p) for p in self.dense}
+        ts += [p.data for p in self.model.parameters() if id(p) not in dense]
+        ts += list(self.model.buffers())
+        for st in self._state.values():
+            ts += [st[k] for k in ("m", "v") if st[k] is not None]
+        return ts
+
+    def _capture(self, idx, labels):
+        """Capture one step reading `idx`/`labels` in place; model and optimizer state are left as they were."""
+        known = set(self._state)
+        snap = [(t, t.clone()) for t in self._mutable_state()]
+        x = self._columns(idx)
+        # warm-up and capture on one stream: autograd's accumulation nodes remember the stream of their first use
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream()
+        side = self._capture_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):          # first launches set kernel attributes, size workspaces and plans
+                self._step_impl(x, labels)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def restore():
+            for t, c in snap:
+                t.copy_(c)
+            for k, st in self._state.items():
+                if k not in known:          # moments created by the warm-up steps start from zero
+                    for name in ("m", "v"):
+                        if st[name] is not None:
+                            st[name].zero_()
+        restore()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool, stream=side):
+            loss = self._step_impl(x, labels)
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        torch.cuda.synchronize()
+        restore()
+        return {"idx": idx, "labels": labels, "graph": g, "loss": loss}
+
     # ------------------------------------------------------------------------------------------
     def step(self, inputs, labels) -> torch.Tensor:
         """BaseModel.train_step signature: dict-of-columns batch and dict of label columns; returns the loss."""
+        if self.use_graph:
+            m = self.model
+            x = m.features_to_divice(inputs)
+            y = m.labels_to_device(labels)
+            if y.dtype not in (torch.int64, torch.float32):
+                y = y.float()
+            return self.step_tensors(m.embedding_layer.index_matrix(x), y.contiguous())
+        return self._step_impl(inputs, self.model.labels_to_device(labels))
+
+    def _step_impl(self, inputs, y) -> torch.Tensor:
         m = self.model
-        y = m.labels_to_device(labels)
         self.flat_g.zero_()
         for p, gv in zip(self.dense, self._gviews):
             p.grad = gv                              # autograd accumulates into the flat buffer in place

@@ -226,14 +226,15 @@ def test_ffm(B, vocabs, d):
         fp.rows(idx, T, gout.view(-1).to(DEV), parts)
         dT2 = torch.zeros_like(T)
         fp.scatter_wide(dT2)
-        assert torch.equal(dT2, dT)
-        close(parts.sum().cpu(), (dT.double() ** 2).sum().float().cpu(), rtol=1e-5, atol=1e-12, msg="norm partials")
+        # (rows spanning several chunks of the plan are summed chunk-wise: same terms, different association)
+        close(dT2, dT, rtol=1e-5, atol=1e-6 * max(1.0, float(dT.abs().max())), msg="touched rows vs dense")
+        close(parts.sum().cpu(), (dT2.double() ** 2).sum().float().cpu(), rtol=1e-5, atol=1e-12, msg="norm partials")
         # SGD on the touched rows == dense SGD
         hyper = ops.make_hyper(DEV, 0.1)
         scal = torch.tensor([0.0, 0.5], device=DEV)
         T2 = T.clone()
         fp.update_wide("SGD", hyper, scal, T2)
-        close(T2, T - 0.1 * 0.5 * dT, rtol=1e-6, atol=1e-7, msg="touched-rows SGD")
+        close(T2, T - 0.1 * 0.5 * dT2, rtol=1e-6, atol=1e-7, msg="touched-rows SGD")
 
 
 def test_unsupported_shapes_raise():

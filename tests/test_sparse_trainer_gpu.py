@@ -26,12 +26,18 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("kind,optimizer,steps,kw", CASES, ids=[f"{c[0]}-{c[1]}-{i}" for i, c in enumerate(CASES)])
-def test_sparse_step_matches_dense_oracle(kind, optimizer, steps, kw):
+GRAPH_CASES = [CASES[0], CASES[3], CASES[6], CASES[8]]
+
+
+@pytest.mark.parametrize("use_graph,kind,optimizer,steps,kw",
+                         [(False, *c) for c in CASES] + [(True, *c) for c in GRAPH_CASES],
+                         ids=[f"{c[0]}-{c[1]}-{i}" for i, c in enumerate(CASES)] +
+                             [f"graph-{c[0]}-{c[1]}" for c in GRAPH_CASES])
+def test_sparse_step_matches_dense_oracle(use_graph, kind, optimizer, steps, kw):
     # the reference's optimizer factory knows SGD / Adam / AdamW only: build with SGD, train with the requested one
     m, rec = build(kind, "SGD", **kw)
     o = make_oracle(kind, m, rec, kw)
-    eng = m.use_sparse_step(optimizer_type=optimizer, lr=1e-2)
+    eng = m.use_sparse_step(optimizer_type=optimizer, lr=1e-2, use_graph=use_graph)
     opt = O.make_optimizer(optimizer, o.parameters(), 1e-2)
     g = torch.Generator().manual_seed(123)
     for step in range(steps):
