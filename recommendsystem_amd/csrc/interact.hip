@@ -768,19 +768,29 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
                                                            float* __restrict__ partials, int region) {
     extern __shared__ float sm[];
     constexpr int ES = D + 1;
+    constexpr int ZS = A + 1, PS = D + 1;        // row strides of the per-pair staging (bank-conflict padding)
+    constexpr int NB = D > 16 ? D / 16 : 1;      // 16-column blocks of dW
     constexpr int NP = A * D + 2 * A + D + 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
     const int T = F / 2;
     float* e = sm + wv * region;
     float* sc = e + F * ES;
     float* gr = sc + T * 64;
-    float accW[A * D], accb[A], acch[A], accpw[D], accpb = 0.f;
+    float* zs = gr + T * 64;                     // [64][ZS]  dL/dz of the lane's pair in this round
+    float* ps = zs + 64 * ZS;                    // [64][PS]  p = e_i * e_j of that pair
+    for (int i = lane; i < 64 * (ZS + PS); i += 64) zs[i] = 0.f;      // lanes >= F never write their rows
+    // dW[a][k] = sum over pairs dz_a * p_k: accumulated over rounds and samples as a [16 x 16*NB] MFMA tile whose
+    // summation index runs over the wave's 64 pair slots (4 per v_mfma_f32_16x16x4_f32)
+    f32x4 accW[NB];
 #pragma unroll
-    for (int i = 0; i < A * D; ++i) accW[i] = 0.f;
+    for (int nb = 0; nb < NB; ++nb) accW[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float accb[A], acch[A], accpw[D], accpb = 0.f;
 #pragma unroll
     for (int i = 0; i < A; ++i) accb[i] = acch[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < D; ++i) accpw[i] = 0.f;
+    const int ksteps = (F + 3) / 4;
 
     for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
         float ej[D];
@@ -825,6 +835,7 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
             float send[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) send[k] = 0.f;
+            __builtin_amdgcn_wave_barrier();                       // last round's staging has been consumed
             if (lane < F) {
                 float ep[D], pk[D], z[A], dp[D];
 #pragma unroll
@@ -833,6 +844,7 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
                 for (int k = 0; k < D; ++k) {
                     ep[k] = e[pr * ES + k];
                     pk[k] = ej[k] * ep[k];
+                    ps[lane * PS + k] = pk[k];
                     dp[k] = a * go * pw[k];
                     accpw[k] = fmaf(go * a, pk[k], accpw[k]);
 #pragma unroll
@@ -842,18 +854,26 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
                 for (int a_ = 0; a_ < A; ++a_) {
                     const bool on = z[a_] > 0.f;
                     const float dz = on ? ds * h[a_] : 0.f;
+                    zs[lane * ZS + a_] = dz;
                     accb[a_] += dz;
                     acch[a_] = fmaf(ds, on ? z[a_] : 0.f, acch[a_]);
 #pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        dp[k] = fmaf(dz, W[a_ * D + k], dp[k]);
-                        accW[a_ * D + k] = fmaf(dz, pk[k], accW[a_ * D + k]);
-                    }
+                    for (int k = 0; k < D; ++k) dp[k] = fmaf(dz, W[a_ * D + k], dp[k]);
                 }
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     de[k] = fmaf(dp[k], ep[k], de[k]);
                     send[k] = dp[k] * ej[k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int s4 = 0; s4 < ksteps; ++s4) {
+                const int pl = 4 * s4 + g4;
+                const float av = r16 < A ? zs[pl * ZS + r16] : 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float bv = 16 * nb + r16 < D ? ps[pl * PS + 16 * nb + r16] : 0.f;
+                    accW[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accW[nb], 0, 0, 0);
                 }
             }
             const bool take = lane < F && afm_active(src, t, F);
@@ -869,14 +889,16 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
             for (int c = 0; c < D / 4; ++c) dst[c] = make_float4(de[4 * c], de[4 * c + 1], de[4 * c + 2], de[4 * c + 3]);
         }
     }
-    // lane partials -> wave sums (fixed shuffle order) -> one row per workgroup (waves added in fixed order)
+    // per-wave results -> one row per workgroup (waves added in fixed order)
     __builtin_amdgcn_wave_barrier();
     float* red = sm + wv * region;
 #pragma unroll
-    for (int i = 0; i < A * D; ++i) {
-        const float t = rs_wave_sum(accW[i]);
-        if (lane == 0) red[i] = t;
-    }
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int a_ = 4 * g4 + v, k = 16 * nb + r16;
+            if (a_ < A && k < D) red[a_ * D + k] = accW[nb][v];
+        }
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         const float tb = rs_wave_sum(accb[i]), th = rs_wave_sum(acch[i]);
@@ -893,7 +915,6 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
     float* prow = partials + (long long)blockIdx.x * NP;
     for (int i = threadIdx.x; i < NP; i += 256) prow[i] = ((sm[i] + sm[region + i]) + sm[2 * region + i]) + sm[3 * region + i];
 }
-
 
 // ---- FFM with true field-aware tables (model/FFM/FFM.py:43-62) -------------------------------------
 // Stacked table T [R, F*d]: row (row_offset[i] + x_i) holds the F vectors of feature value x_i, one per
@@ -1153,9 +1174,10 @@ int pnn_mfma_grid(int B) { const int g = rs_cdiv(B, 4); return g > 2048 ? 2048 :
 bool afm_wave_shape(int d, int A) {
     return (d == 4 || d == 8 || d == 16 || d == 32) && (A == 4 || A == 8 || A == 16) && A * d <= 256;
 }
-// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays; at least one parameter-gradient row.
-int afm_region_floats(int F, int d, int A) {
-    const int need = F * (d + 1) + 2 * (F / 2) * 64, np = A * d + 2 * A + d + 1;
+// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays, the backward's per-pair staging
+// [64][A+1 + d+1]; at least one parameter-gradient row.
+int afm_region_floats(int F, int d, int A, bool bwd) {
+    const int need = F * (d + 1) + 2 * (F / 2) * 64 + (bwd ? 64 * (A + 1 + d + 1) : 0), np = A * d + 2 * A + d + 1;
     return need > np ? need : np;
 }
 #define RS_AFM_CASE(K, DD, AA) case (DD) * 100 + (AA): K(DD, AA); break;
@@ -1337,7 +1359,7 @@ int rs_afm_fwd(const float* emb, int B, int F, int d, int A, const float* W, con
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && W && bA && h && pw && pb && out, "rs_afm_fwd: null argument");
     if (F <= 64 && afm_wave_shape(d, A) && (reinterpret_cast<uintptr_t>(emb) & 15) == 0) {
-        const int region = afm_region_floats(F, d, A);
+        const int region = afm_region_floats(F, d, A, false);
         const int wgrid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
 #define RS_AFM_FW(DD, AA)                                                                                              \
     hipLaunchKernelGGL((afm_fwd_wave_kernel<DD, AA>), dim3(wgrid), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, \
@@ -1372,10 +1394,14 @@ int rs_afm_bwd(const float* emb, const float* dout, int B, int F, int d, int A, 
     RS_CHECK_ARG(emb && dout && W && bA && h && pw && demb && partials, "rs_afm_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_afm_bwd: partials must have %d rows", rs_interact_partial_rows(B));
     if (F <= 64 && afm_wave_shape(d, A) && ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(demb)) & 15) == 0) {
-        const int region = afm_region_floats(F, d, A);
+        const int region = afm_region_floats(F, d, A, true);
+        RS_CHECK_ARG((size_t)4 * region * sizeof(float) <= LDS_BIG, "rs_afm_bwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);
 #define RS_AFM_BW(DD, AA)                                                                                              \
-    hipLaunchKernelGGL((afm_bwd_wave_kernel<DD, AA>), dim3(rows), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, \
-                       dout, B, F, W, bA, h, pw, demb, partials, region)
+    do {                                                                                                               \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(afm_bwd_wave_kernel<DD, AA>)), "rs_afm_bwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL((afm_bwd_wave_kernel<DD, AA>), dim3(rows), dim3(256), (size_t)4 * region * sizeof(float), stream, \
+                           emb, dout, B, F, W, bA, h, pw, demb, partials, region);                                     \
+    } while (0)
         RS_AFM_DISPATCH(RS_AFM_BW)
 #undef RS_AFM_BW
         RS_CHECK_LAUNCH("rs_afm_bwd");
