@@ -164,10 +164,14 @@ def main():
 
     model, rec, hidden = build(args, device)
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
-    if use_dist:
+    fused_kind = getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep")
+    if use_dist and fused_kind:
         from recommendsystem_amd.dist import DistributedTrainer
         eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.dist_graph), stage_cpu=rehearse)
-    elif getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep"):
+    elif use_dist:
+        from recommendsystem_amd.dist import DistributedSparseTrainer
+        eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
+    elif fused_kind:
         eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
     else:
         eng = model.use_sparse_step(use_graph=bool(args.graph))

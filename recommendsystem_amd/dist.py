@@ -24,6 +24,7 @@ import torch.distributed as dist
 from . import ops
 from ._lib import RSError, call, ptr, stream
 from .engine import FusedTrainer, N_DENSE_PARTIALS
+from .sparse_trainer import SparseTrainer
 from .ops import FieldLayout, SparsePlan
 
 
@@ -456,3 +457,123 @@ class DistributedTrainer(FusedTrainer):
         for ex in self._ex.values():
             ex.check_overflow()
             ex.k.layout_own.check_indices()
+
+
+# -------------------------------------------------------------------------------------------------
+# the distributed generic step (any model kind)
+# -------------------------------------------------------------------------------------------------
+class _ShardedLookups:
+    """TableCapture provider: rows and LR terms come from the row-sharded tables through the exchange."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+
+    def emb(self, idx, holder):
+        st, ex = self.t._sharded(holder, "emb", idx.shape[1])
+        F, B = idx.shape
+        out = torch.empty((B, F, holder.dim), dtype=torch.float32, device=idx.device)
+        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None)
+        return out
+
+    def lr_terms(self, idx, holder):
+        st, ex = self.t._sharded(holder, "lr", idx.shape[1])
+        F, B = idx.shape
+        out = torch.empty((B, F), dtype=torch.float32, device=idx.device)
+        ex.forward(idx, None, st["shard"], None, out.view(-1))
+        return out
+
+
+class DistributedSparseTrainer(SparseTrainer):
+    """SparseTrainer over row-sharded tables and a data-parallel dense part: the multi-GPU step for the model kinds
+    the fused engine does not schedule (PNN, NFM, AFM, DCN, DeepCrossing, ...).  Same protocol as DistributedTrainer:
+    per looked-up table three all-to-alls (distinct keys out, rows back, one gradient per distinct key out), one
+    all-reduce of the flat dense gradient with the tables' ||g||^2 riding behind it, mean loss over the N*B samples.
+    Every rank must build the same model from the same seed.  FFM's field-aware rows are not exchanged yet."""
+
+    def __init__(self, model, group=None, stage_cpu: bool = False, bucket_slack: float = 1.5, **kw):
+        if kw.pop("use_graph", False):
+            raise RSError("DistributedSparseTrainer: the step is issued eagerly (collectives between the launches)")
+        self.comm = Comm(group, stage_cpu=stage_cpu)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        self.bucket_slack = bucket_slack
+        super().__init__(model, **kw)
+        self._shards = {}
+        self._provider = _ShardedLookups(self)
+        self.comm.broadcast(self.flat_w, 0)          # the dense part must start identical on every rank
+
+    def _sharded(self, holder, kind, B):
+        st = self._shards.get(id(holder))
+        if st is None:
+            spec = ShardSpec(holder.layout.vocab_sizes, self.world, self.rank)
+            shard = spec.shard_table(holder.stacked)
+            if kind == "lr":
+                shard = shard.view(-1)
+            st = {"holder": holder, "kind": kind, "spec": spec, "shard": shard,
+                  "m": torch.zeros_like(shard) if self.need_m else None,
+                  "v": torch.zeros_like(shard) if self.need_v else None, "ex": {}}
+            self._shards[id(holder)] = st
+        ex = st["ex"].get(B)
+        if ex is None:
+            spec = st["spec"]
+            cap_b = spec.bucket_capacity(B, slack=self.bucket_slack)
+            emb = kind == "emb"
+            k = HipShardKernels(spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
+            ex = ShardedExchange(k, self.comm, spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
+            ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
+            st["ex"][B] = ex
+        return st, ex
+
+    def _step_impl(self, inputs, y) -> torch.Tensor:
+        cap, loss = self._forward_backward(inputs, y, provider=self._provider, grad_scale=1.0 / self.world)
+        jobs, seen = [], set()
+        for rec in cap.records:
+            g = rec["out"].grad
+            if g is None:
+                continue
+            if rec["kind"] == "ffm":
+                raise RSError("DistributedSparseTrainer: FFM's field-aware rows are not row-sharded yet")
+            if id(rec["holder"]) in seen:
+                raise RSError("DistributedSparseTrainer: a table was looked up twice in one forward pass")
+            seen.add(id(rec["holder"]))
+            B = rec["idx"].shape[1]
+            st, ex = self._sharded(rec["holder"], rec["kind"], B)
+            if rec["kind"] == "emb":
+                ex.backward(g.contiguous().view(B * ex.F, ex.d), None, None, None, None, ex.own_partials)
+            else:
+                ex.backward(None, None, None, None, g.contiguous().view(B), ex.own_partials)
+            jobs.append((st, ex))
+        # ||g||^2 of the owned rows of every table (ranks own disjoint rows) rides behind the dense gradients
+        if jobs:
+            allp = torch.cat([ex.own_partials for _, ex in jobs]) if len(jobs) > 1 else jobs[0][1].own_partials
+            ops.colsum(allp.view(-1, 1), out=self.flat_g_ext[-4:-3])
+        self.comm.all_reduce(self.flat_g_ext)
+        if self._partials is None or self._partials.numel() != N_DENSE_PARTIALS + 1:
+            self._partials = torch.zeros(N_DENSE_PARTIALS + 1, dtype=torch.float32, device=self.device)
+        P = self._partials
+        P[0:1].copy_(self.flat_g_ext[-4:-3])
+        ops.sumsq_partials(self.flat_g, P[1:])
+        ops.clip_and_prepare(P, self.max_norm, self.scal, self.step_count, self.hyper)
+        ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
+        for st, ex in jobs:
+            if st["kind"] == "emb":
+                ex.k.update(self.opt, self.hyper, self.scal, st["shard"], st["m"], st["v"], None, None, None)
+            else:
+                ex.k.update(self.opt, self.hyper, self.scal, None, None, None, st["shard"], st["m"], st["v"])
+        self.last = {"records": cap.records}
+        return loss.detach()
+
+    def sync_to_model(self):
+        """All-gather the shards into the model's (replicated) table parameters."""
+        for st in self._shards.values():
+            shard = st["shard"].view(-1, 1) if st["kind"] == "lr" else st["shard"]
+            n = torch.tensor([shard.shape[0]], dtype=torch.int64, device=shard.device)
+            ns = [int(x.item()) for x in self.comm.all_gather(n)]
+            pad = torch.zeros((max(ns),) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+            pad[:shard.shape[0]] = shard
+            st["spec"].unshard_into(st["holder"].stacked, [g[:k] for g, k in zip(self.comm.all_gather(pad), ns)])
+
+    def check(self):
+        for st in self._shards.values():
+            for ex in st["ex"].values():
+                ex.check_overflow()
+                ex.k.layout_own.check_indices()

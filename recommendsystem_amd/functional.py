@@ -68,8 +68,11 @@ class TableCapture:
 
     active = None
 
-    def __init__(self):
+    def __init__(self, provider=None):
+        # provider: object with emb(idx, holder) -> [B, F, d] and lr_terms(idx, holder) -> [B, F] (the per-field
+        # 1-dim values) that fetches rows from somewhere else than the local stacked table (row-sharded tables)
         self.records = []
+        self.provider = provider
 
     def __enter__(self):
         if TableCapture.active is not None:
@@ -90,6 +93,8 @@ class TableCapture:
 def embedding_lookup(idx, holder, weights) -> torch.Tensor:
     cap = TableCapture.active
     if cap is not None:
+        if cap.provider is not None:
+            return cap.record("emb", holder, idx, cap.provider.emb(idx, holder))
         return cap.record("emb", holder, idx, ops.gather_fwd(idx, holder.layout, holder.stacked_for(weights)))
     return _GatherFn.apply(idx, holder, *weights)
 
@@ -139,8 +144,14 @@ class _BiasGradFn(torch.autograd.Function):
 def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
     cap = TableCapture.active
     if cap is not None:
-        stacked1 = holder.stacked_for(weights1)
-        raw = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias.detach(), want_emb=False, want_lr=True)["lr"]
+        if cap.provider is not None:
+            terms = cap.provider.lr_terms(idx, holder)            # [B, F]
+            ones = torch.ones(terms.shape[1], dtype=torch.float32, device=terms.device)
+            raw = ops.rowdot_fwd(terms, ones, bias.detach(), 0)     # sum_f w_f[idx] + bias
+        else:
+            stacked1 = holder.stacked_for(weights1)
+            raw = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias.detach(), want_emb=False,
+                                       want_lr=True)["lr"]
         return _BiasGradFn.apply(cap.record("lr", holder, idx, raw).view(-1, 1), bias)
     return _LRFn.apply(idx, holder, bias, *weights1)
 

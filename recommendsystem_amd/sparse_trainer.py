@@ -83,7 +83,10 @@ class SparseTrainer:
             offs.append(o)
             o += (p.numel() + 3) // 4 * 4
         self.flat_w = torch.zeros(max(o, 4), dtype=torch.float32, device=self.device)
-        self.flat_g = torch.zeros_like(self.flat_w)
+        # four spare floats behind the gradients: the multi-GPU trainer sends its scalar reductions along with the
+        # one all-reduce of this buffer
+        self.flat_g_ext = torch.zeros(self.flat_w.numel() + 4, dtype=torch.float32, device=self.device)
+        self.flat_g = self.flat_g_ext[:self.flat_w.numel()]
         self._gviews = []
         with torch.no_grad():
             for p, off in zip(self.dense, offs):
@@ -200,17 +203,22 @@ class SparseTrainer:
             return self.step_tensors(m.embedding_layer.index_matrix(x), y.contiguous())
         return self._step_impl(inputs, self.model.labels_to_device(labels))
 
-    def _step_impl(self, inputs, y) -> torch.Tensor:
+    def _forward_backward(self, inputs, y, provider=None, grad_scale: float = 1.0):
+        """The model's forward and autograd backward with captured table lookups; dense gradients land in flat_g."""
         m = self.model
-        self.flat_g.zero_()
+        self.flat_g_ext.zero_()
         for p, gv in zip(self.dense, self._gviews):
             p.grad = gv                              # autograd accumulates into the flat buffer in place
-        with Fn.TableCapture() as cap:
+        with Fn.TableCapture(provider) as cap:
             out = m.forward(inputs)
             loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
                 loss = loss + m.regularization_loss()
-            loss.backward()
+            (loss if grad_scale == 1.0 else loss * grad_scale).backward()
+        return cap, loss
+
+    def _step_impl(self, inputs, y) -> torch.Tensor:
+        cap, loss = self._forward_backward(inputs, y)
         seen = set()
         jobs = []
         n_total = N_DENSE_PARTIALS

@@ -1,9 +1,10 @@
 """One rank of the multi-process tests (started by test_dist_cpu.py / test_dist_gpu.py).
 
     python dist_worker.py cpu <outdir>     host-side exchange protocol under gloo with torch-CPU stand-in kernels
-    python dist_worker.py gpu <outdir> <kind> <optimizer> [graph]
-                                           DistributedTrainer on cuda:0 (all ranks share the one GPU of the
-                                           test box), gloo with host staging in place of RCCL
+    python dist_worker.py gpu <outdir> <kind> <optimizer> [graph|generic]
+                                           DistributedTrainer (generic: DistributedSparseTrainer) on cuda:0 (all
+                                           ranks share the one GPU of the test box), gloo with host staging in
+                                           place of RCCL
 
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment.
 """
@@ -122,32 +123,58 @@ def run_cpu(outdir):
     open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
 
 
-def run_gpu(outdir, kind, optimizer, use_graph=False):
+GPU_VOCAB = [7, 50, 3, 400, 1000, 23, 5000, 64]
+GPU_BATCH, GPU_DIM, GPU_STEPS = 256, 8, 3
+
+
+def build_gpu_model(kind, optimizer, batch):
+    """The model of the multi-process GPU tests (same seed on every rank and in the single-GPU reference)."""
     from recommendsystem_amd import data, models
     from recommendsystem_amd.base_model import random_all
-    from recommendsystem_amd.dist import DistributedTrainer
-    rank, N = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    vocab = [7, 50, 3, 400, 1000, 23, 5000, 64]
-    batch, d, steps = 256, 8, 3
+    vocab = GPU_VOCAB
     random_all(11)
-    rec = data.criteo_x1_recorder(embedding_dim=d, batch_size=batch, vocab_sizes=vocab)
+    rec = data.criteo_x1_recorder(embedding_dim=GPU_DIM, batch_size=batch, vocab_sizes=vocab)
     kw = dict(optimizer_type=optimizer if optimizer != "Adagrad" else "SGD")
+    hid = dict(hidden_dim_list=[64, 32], normalization=None)
     if kind == "deepfm":
-        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+        m = models.DeepFM(rec, 1e-2, 0, **hid, **kw)
     elif kind == "fm":
         m = models.FM(rec, 1e-2, 0, **kw)
     elif kind == "lr":
         m = models.LR(rec, 1e-2, 0, **kw)
+    elif kind == "dnn":
+        m = models.DNN(rec, 1e-2, 0, **hid, **kw)
+    elif kind == "pnn":
+        m = models.PNN(rec, 1e-2, 0, pnn_type="inner", **hid, **kw)
+    elif kind == "dcn":
+        m = models.DCN(rec, 1e-2, 0, cross_layers_num=2, **hid, **kw)
+    elif kind == "nfm":
+        m = models.NFM(rec, 1e-2, 0, hidden_dim=4, **hid, **kw)
+    elif kind == "afm":
+        m = models.AFM(rec, 1e-2, 0, attention_dim=4, **kw)
     else:
-        m = models.DNN(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
+        raise ValueError(kind)
     # larger initial rows than the reference's 1e-4 so that every term of the gradient matters
     with torch.no_grad():
-        for p in m.parameters():
-            if p.dim() == 2 and p.shape[0] in vocab:
+        for n, p in m.named_parameters():
+            if p.dim() == 2 and p.shape[0] in vocab and "embedded" in n:
                 p[1:].normal_(0, 0.05)
+            if n == "v" or n.startswith("cross."):
+                p.mul_(0.2)
     m.train()
-    eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
+    return m
+
+
+def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False):
+    from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer
+    rank, N = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    vocab, batch, steps = GPU_VOCAB, GPU_BATCH, GPU_STEPS
+    m = build_gpu_model(kind, optimizer, batch)
+    if generic:
+        eng = DistributedSparseTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
+    else:
+        eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
     losses = []
     for s in range(steps):
         idx, y = rank_batch(rank + 10 * s, vocab, batch, zero_every=17)
@@ -169,6 +196,7 @@ if __name__ == "__main__":
         if mode == "cpu":
             run_cpu(outdir)
         else:
-            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=len(sys.argv) > 5 and sys.argv[5] == "graph")
+            extra = sys.argv[5] if len(sys.argv) > 5 else ""
+            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=extra == "graph", generic=extra == "generic")
     finally:
         dist.destroy_process_group()

@@ -14,28 +14,14 @@ from dist_worker import rank_batch
 pytestmark = pytest.mark.gpu
 
 
-def single_gpu_reference(kind, optimizer, world):
-    from recommendsystem_amd import data, models
-    from recommendsystem_amd.base_model import random_all
-    vocab = [7, 50, 3, 400, 1000, 23, 5000, 64]
-    batch, d, steps = 256, 8, 3
-    random_all(11)
-    rec = data.criteo_x1_recorder(embedding_dim=d, batch_size=batch * world, vocab_sizes=vocab)
-    kw = dict(optimizer_type=optimizer if optimizer != "Adagrad" else "SGD")
-    if kind == "deepfm":
-        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
-    elif kind == "fm":
-        m = models.FM(rec, 1e-2, 0, **kw)
-    elif kind == "lr":
-        m = models.LR(rec, 1e-2, 0, **kw)
+def single_gpu_reference(kind, optimizer, world, generic=False):
+    from dist_worker import GPU_BATCH, GPU_STEPS, GPU_VOCAB, build_gpu_model
+    vocab, batch, steps = GPU_VOCAB, GPU_BATCH, GPU_STEPS
+    m = build_gpu_model(kind, optimizer, batch * world)
+    if generic:
+        eng = m.use_sparse_step(max_norm=0.05, optimizer_type=optimizer)
     else:
-        m = models.DNN(rec, 1e-2, 0, hidden_dim_list=[64, 32], normalization=None, **kw)
-    with torch.no_grad():
-        for p in m.parameters():
-            if p.dim() == 2 and p.shape[0] in vocab:
-                p[1:].normal_(0, 0.05)
-    m.train()
-    eng = m.use_fused_step(mode="sparse", max_norm=0.05, optimizer_type=optimizer)
+        eng = m.use_fused_step(mode="sparse", max_norm=0.05, optimizer_type=optimizer)
     losses = []
     for s in range(steps):
         parts = [rank_batch(r + 10 * s, vocab, batch, zero_every=17) for r in range(world)]
@@ -56,6 +42,22 @@ def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, graph, tmp_path
     got = np.load(tmp_path / "state.npz")
     m, losses = single_gpu_reference(kind, optimizer, world)
     # mean loss over the union batch = mean of the ranks' local means (equal batch sizes)
+    lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
+    np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("kind,optimizer", [("pnn", "Adam"), ("dcn", "SGD"), ("nfm", "Adagrad"), ("afm", "AdamW")])
+def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tmp_path):
+    """DistributedSparseTrainer (model forward under autograd, sharded lookups) against SparseTrainer on the union."""
+    world = 2
+    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer, "generic"], timeout=200)
+    assert codes == [0] * world, "\n".join(outs)
+    got = np.load(tmp_path / "state.npz")
+    m, losses = single_gpu_reference(kind, optimizer, world, generic=True)
     lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
     np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
     for k, v in m.state_dict().items():
