@@ -52,8 +52,9 @@ def parse():
                    help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
                         "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
     p.add_argument("--dist-graph", type=int, default=0,
-                   help="N>1: replay the kernels between the collectives as HIP-graph segments (default: eager; measured "
-                        "slower than eager on one rank, unmeasured on eight)")
+                   help="N>1: 0 = eager (default); 1 = HIP-graph segments between the collectives (measured slower than "
+                        "eager on one rank); 2 = one HIP graph with the RCCL collectives captured inside (measured on one "
+                        "rank only)")
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
@@ -167,7 +168,7 @@ def main():
     fused_kind = getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep")
     if use_dist and fused_kind:
         from recommendsystem_amd.dist import DistributedTrainer
-        eng = DistributedTrainer(model, mode=args.mode, use_graph=bool(args.dist_graph), stage_cpu=rehearse)
+        eng = DistributedTrainer(model, mode=args.mode, use_graph={0: False, 1: True, 2: "full"}[args.dist_graph], stage_cpu=rehearse)
     elif use_dist:
         from recommendsystem_amd.dist import DistributedSparseTrainer
         eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
@@ -315,7 +316,12 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if use_dist:
+        import gc
         import torch.distributed as dist
+        # graphs that captured collectives go before the communicator does
+        getattr(eng, "_graphs", {}).clear()
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -392,7 +392,12 @@ class DistributedTrainer(FusedTrainer):
     # ---- HIP-graph segments between the collectives --------------------------------------------------
     def _capture(self, idx, labels):
         """Record one step reading `idx`/`labels` in place as graph segments + collectives; the training state is
-        left as it was (the warm-up steps run for real -- collectives included, on every rank -- and are undone)."""
+        left as it was (the warm-up steps run for real -- collectives included, on every rank -- and are undone).
+        use_graph="full": one HIP graph for the whole step with the RCCL collectives captured inside it (other
+        threads of the process group, such as its watchdog, keep working during capture)."""
+        if self.use_graph == "full":
+            self._capture_error_mode = "thread_local"
+            return FusedTrainer._capture(self, idx, labels)
         ent = {"idx": idx, "labels": labels}
         snap = [(t, t.clone()) for t in self._mutable_state()]
         s = torch.cuda.Stream()

@@ -131,6 +131,7 @@ class FusedTrainer:
         self.ws_sort = ops.Workspace(dev)
         self._graphs = {}
         self._graph_pool = None
+        self._capture_error_mode = "global"
         self.last = {}
 
     # ------------------------------------------------------------------------------------------
@@ -511,7 +512,8 @@ class FusedTrainer:
         for t, c in snap:
             t.copy_(c)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool), ops.use_workspace(self.ws):
+        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=self._capture_error_mode), \
+                ops.use_workspace(self.ws):
             ent["loss"] = self._step_impl(idx, labels)
         if self._graph_pool is None:
             self._graph_pool = g.pool()
