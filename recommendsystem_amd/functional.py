@@ -73,6 +73,16 @@ class TableCapture:
         # 1-dim values) that fetches rows from somewhere else than the local stacked table (row-sharded tables)
         self.records = []
         self.provider = provider
+        self._idx = {}           # (id of the batch dict, columns) -> (batch dict, index matrix): one stack per forward
+
+    def index_matrix(self, x, cols, build):
+        """The columnar index matrix of batch dict `x` for `cols`, built once per forward pass: lookups of the
+        same batch then share one tensor (and the trainer one sort)."""
+        key = (id(x), tuple(cols))
+        hit = self._idx.get(key)
+        if hit is None:
+            hit = self._idx[key] = (x, build())
+        return hit[1]
 
     def __enter__(self):
         if TableCapture.active is not None:

@@ -131,7 +131,11 @@ class Embedding_layer(nn.Module):
 
     def index_matrix(self, x) -> torch.Tensor:
         """dict of column tensors -> columnar [F, B] int64 matrix on the table's device."""
-        idx = Fn.stack_columns(x, self._cols)
+        cap = Fn.TableCapture.active
+        if cap is not None:
+            idx = cap.index_matrix(x, self._cols, lambda: Fn.stack_columns(x, self._cols))
+        else:
+            idx = Fn.stack_columns(x, self._cols)
         if not idx.is_cuda:
             raise RSError("Embedding_layer: batch tensors are on the CPU; move them to the device first "
                           "(BaseModel.features_to_divice does)")

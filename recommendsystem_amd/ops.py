@@ -751,8 +751,8 @@ def ffm_bwd(plan: "SparsePlan", idx: torch.Tensor, T: torch.Tensor, dout: torch.
 class FFMPlan(SparsePlan):
     """Sort plan of a batch plus the compact buffer of field-aware row gradients (rows of F*d floats)."""
 
-    def __init__(self, layout: FieldLayout, cap: int, d: int, device=None):
-        super().__init__(layout, cap, 1, with_lr=False, device=device)
+    def __init__(self, layout: FieldLayout, cap: int, d: int, with_lr: bool = False, device=None):
+        super().__init__(layout, cap, 1, with_lr=with_lr, device=device)
         if d % 4:
             raise RSError(f"FFM touched-rows update: embedding_dim {d} is not a multiple of 4")
         self.ffm_d = int(d)

@@ -109,17 +109,43 @@ class SparseTrainer:
             self._state[id(holder)] = st
         return st
 
-    def _plan(self, rec, B):
-        holder, kind = rec["holder"], rec["kind"]
-        key = (id(holder), kind, B)
+    def _plan(self, group, B):
+        """One sort plan per group of lookups that share a batch (same index matrix and field vocabularies)."""
+        key = (tuple(sorted((id(r["holder"]), r["kind"]) for r in group.values())), B)
         p = self._plans.get(key)
         if p is None:
-            if kind == "ffm":
-                p = ops.FFMPlan(holder.layout, cap=B, d=holder.dim // holder.layout.num_fields)
+            any_rec = next(iter(group.values()))
+            layout = any_rec["holder"].layout
+            if "ffm" in group:
+                h = group["ffm"]["holder"]
+                p = ops.FFMPlan(layout, cap=B, d=h.dim // layout.num_fields, with_lr="lr" in group)
             else:
-                p = ops.SparsePlan(holder.layout, cap=B, d=holder.dim if kind == "emb" else 1, with_lr=(kind == "lr"))
+                p = ops.SparsePlan(layout, cap=B, d=group["emb"]["holder"].dim if "emb" in group else 1,
+                                   with_lr="lr" in group)
             self._plans[key] = p
         return p
+
+    @staticmethod
+    def _groups(records):
+        """Records with a gradient, grouped by shared index matrix: at most one lookup of each kind per group, and
+        an FFM lookup does not share a plan with an embedding lookup (different chunk windows)."""
+        groups, seen = [], set()
+        for rec in records:
+            if rec["out"].grad is None:
+                continue
+            if id(rec["holder"]) in seen:
+                raise RSError("SparseTrainer: a table was looked up twice in one forward pass")
+            seen.add(id(rec["holder"]))
+            for g in groups:
+                first = next(iter(g.values()))
+                if (first["idx"] is rec["idx"] and rec["kind"] not in g
+                        and first["holder"].layout.vocab_sizes == rec["holder"].layout.vocab_sizes
+                        and not ({"emb", "ffm"} <= set(g) | {rec["kind"]})):
+                    g[rec["kind"]] = rec
+                    break
+            else:
+                groups.append({rec["kind"]: rec})
+        return groups
 
     def step_tensors(self, idx: torch.Tensor, labels: torch.Tensor, resident: bool = False) -> torch.Tensor:
         """One step on a device-resident columnar batch (idx [F, B] int64 in the embedding layer's column order,
@@ -219,49 +245,48 @@ class SparseTrainer:
 
     def _step_impl(self, inputs, y) -> torch.Tensor:
         cap, loss = self._forward_backward(inputs, y)
-        seen = set()
         jobs = []
         n_total = N_DENSE_PARTIALS
-        for rec in cap.records:
-            g = rec["out"].grad
-            if g is None:
-                continue
-            if id(rec["holder"]) in seen:
-                raise RSError("SparseTrainer: a table was looked up twice in one forward pass")
-            seen.add(id(rec["holder"]))
-            B = rec["idx"].shape[1]
-            plan = self._plan(rec, B)
-            n = plan.n_partials_wide if rec["kind"] == "ffm" else plan.n_partials
-            jobs.append((rec, plan, g, n))
+        for group in self._groups(cap.records):
+            B = next(iter(group.values()))["idx"].shape[1]
+            plan = self._plan(group, B)
+            n = plan.n_partials + (plan.n_partials_wide if "ffm" in group else 0)
+            jobs.append((group, plan, n))
             n_total += n
         if self._partials is None or self._partials.numel() != n_total:
             self._partials = torch.zeros(n_total, dtype=torch.float32, device=self.device)
         P = self._partials
         off = 0
-        for rec, plan, g, n in jobs:
-            idx, kind = rec["idx"], rec["kind"]
+        for group, plan, n in jobs:
+            idx = next(iter(group.values()))["idx"]
             B = idx.shape[1]
-            if kind == "emb":
-                plan.sort_columnar(idx)
-                plan.reduce(P[off:off + n], gout=g.contiguous().view(B * plan.F, plan.d))
-            elif kind == "lr":
-                plan.sort_columnar(idx)
-                plan.reduce(P[off:off + n], dlr=g.contiguous().view(B))
+            grad = lambda kind: group[kind]["out"].grad.contiguous() if kind in group else None
+            if "ffm" in group:
+                nw = plan.n_partials_wide
+                plan.rows(idx, group["ffm"]["holder"].stacked, grad("ffm").view(B), P[off:off + nw])     # sorts
+                if "lr" in group:
+                    plan.reduce(P[off + nw:off + n], dlr=grad("lr").view(B))
+                else:
+                    P[off + nw:off + n].zero_()
             else:
-                plan.rows(idx, rec["holder"].stacked, g.contiguous().view(B), P[off:off + n])
+                plan.sort_columnar(idx)
+                ge, gl = grad("emb"), grad("lr")
+                plan.reduce(P[off:off + n], gout=ge.view(B * plan.F, plan.d) if ge is not None else None,
+                            dlr=gl.view(B) if gl is not None else None)
             off += n
         ops.sumsq_partials(self.flat_g, P[off:off + N_DENSE_PARTIALS])
         ops.clip_and_prepare(P, self.max_norm, self.scal, self.step_count, self.hyper)
         ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
-        for rec, plan, g, n in jobs:
-            st = self._table_state(rec["holder"])
-            if rec["kind"] == "emb":
-                plan.update(self.opt, self.hyper, self.scal, table=st["w"], m=st["m"], v=st["v"])
-            elif rec["kind"] == "lr":
-                plan.update(self.opt, self.hyper, self.scal, table1=st["w"].view(-1),
-                            m1=st["m"].view(-1) if st["m"] is not None else None,
-                            v1=st["v"].view(-1) if st["v"] is not None else None)
-            else:
-                plan.update_wide(self.opt, self.hyper, self.scal, st["w"], st["m"], st["v"])
+        for group, plan, n in jobs:
+            st = {k: self._table_state(r["holder"]) for k, r in group.items()}
+            if "ffm" in group:
+                plan.update_wide(self.opt, self.hyper, self.scal, st["ffm"]["w"], st["ffm"]["m"], st["ffm"]["v"])
+            e, l = st.get("emb"), st.get("lr")
+            if e is not None or l is not None:
+                flat = lambda t: t.view(-1) if t is not None else None
+                plan.update(self.opt, self.hyper, self.scal,
+                            table=e["w"] if e else None, m=e["m"] if e else None, v=e["v"] if e else None,
+                            table1=flat(l["w"]) if l else None, m1=flat(l["m"]) if l else None,
+                            v1=flat(l["v"]) if l else None)
         self.last = {"records": cap.records}
         return loss.detach()
