@@ -173,7 +173,7 @@ def main():
         from recommendsystem_amd.dist import DistributedSparseTrainer
         eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
     elif fused_kind:
-        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=bool(args.overlap))
+        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=int(args.overlap))
     else:
         eng = model.use_sparse_step(use_graph=bool(args.graph))
 

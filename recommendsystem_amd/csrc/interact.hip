@@ -171,27 +171,33 @@ __global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __
     }
 }
 
-// Backward: demb = Gs E.  A operand of step s, row block I: Gs[16I + r][4s + g], gathered from the sample's dP row
-// through pair slots that do not depend on the sample (computed once per wave); B operand: E[4s + g][16c + r].
+// Backward: demb = Gs E.  The sample's dP row is copied to LDS with coalesced reads; the A operand of step s, row
+// block I -- Gs[16I + r][4s + g] -- is gathered from there through pair slots that do not depend on the sample
+// (computed once per wave); B operand: E[4s + g][16c + r], straight from HBM (256 contiguous bytes per request).
 template <int NB, int D>
 __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
                                                                  int B, int F, float* __restrict__ demb) {
+    extern __shared__ float sm[];
     constexpr int KS = NB * 4;
     constexpr int NC = D >= 16 ? D / 16 : 1;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int nwaves = gridDim.x * 4;
     const int fd = F * D, P = F * (F - 1) / 2;
+    float* gl = sm + (threadIdx.x >> 6) * (P + 1);         // this wave's dP row; slot P holds 0 (diagonal / padding)
     int slot[NB][KS];
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int s4 = 0; s4 < KS; ++s4) {
             const int i = 16 * I + r, k = 4 * s4 + g;
-            slot[I][s4] = (i < F && k < F && i != k) ? pair_index_any(i, k, F) : -1;
+            slot[I][s4] = (i < F && k < F && i != k) ? pair_index_any(i, k, F) : P;
         }
+    if (lane == 0) gl[P] = 0.f;
     for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
         const float* e = emb + (long long)b * fd;
         const float* gs = dout + (long long)b * P;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < P; i += 64) gl[i] = gs[i];
         float bv[KS][NC];
 #pragma unroll
         for (int s4 = 0; s4 < KS; ++s4)
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
                 const int k = 4 * s4 + g, col = 16 * c + r;
                 bv[s4][c] = (k < F && col < D) ? e[k * D + col] : 0.f;
             }
+        __builtin_amdgcn_wave_barrier();
         float* o = demb + (long long)b * fd;
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
 #pragma unroll
             for (int s4 = 0; s4 < KS; ++s4) {
                 if (4 * s4 < F) {
-                    const float a = slot[I][s4] >= 0 ? gs[slot[I][s4]] : 0.f;
+                    const float a = gl[slot[I][s4]];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[s4][c], acc[c], 0, 0, 0);
                 }
@@ -365,6 +372,126 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restr
     }
 }
 
+// Register forms of the two cross-network kernels for D <= 64*T and L <= 4 layers: a lane keeps its T elements of
+// x0, x_l (forward) or of dx, d0 and of the 2*L parameter-gradient accumulators (backward) in registers; w and b sit
+// in LDS once per workgroup.  Same per-element arithmetic and the same summation orders as the LDS kernels above.
+template <int T, int L>
+__global__ __launch_bounds__(256) void dcn_cross_fwd_reg_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int B, int D,
+                                                                float* __restrict__ out, float* __restrict__ S) {
+    extern __shared__ float sm[];
+    float* sw = sm;
+    float* sbias = sm + L * D;
+    for (int i = threadIdx.x; i < L * D; i += 256) { sw[i] = w[i]; sbias[i] = bias[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += gridDim.x * 4) {
+        const float* xs = x0 + (long long)b * D;
+        float x0r[T], x[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            x0r[i] = n < D ? xs[n] : 0.f;
+            x[i] = x0r[i];
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int n = lane + 64 * i;
+                if (n < D) part = fmaf(x[i], sw[l * D + n], part);
+            }
+            const float s = rs_wave_sum(part);
+            if (lane == 0 && S) S[(long long)b * L + l] = s;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int n = lane + 64 * i;
+                if (n < D) x[i] = x0r[i] * s + sbias[l * D + n] + x[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            if (n < D) out[(long long)b * D + n] = x[i];
+        }
+    }
+}
+
+template <int T, int L>
+__global__ __launch_bounds__(256) void dcn_cross_bwd_reg_kernel(const float* __restrict__ x0, const float* __restrict__ S,
+                                                                const float* __restrict__ dout, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int B, int D,
+                                                                float* __restrict__ dx0, float* __restrict__ partials) {
+    extern __shared__ float sm[];        // first w | bias, at the end the four waves' accumulators [4][2*L*D]
+    float* sw = sm;
+    float* sbias = sm + L * D;
+    for (int i = threadIdx.x; i < L * D; i += 256) { sw[i] = w[i]; sbias[i] = bias[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float accW[L][T], accB[L][T];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int i = 0; i < T; ++i) accW[l][i] = accB[l][i] = 0.f;
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        const float* xs = x0 + (long long)b * D;
+        float sv[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) sv[l] = S[(long long)b * L + l];
+        float x0r[T], dx[T], d0[T];
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            x0r[i] = n < D ? xs[n] : 0.f;
+            dx[i] = n < D ? dout[(long long)b * D + n] : 0.f;
+            d0[i] = 0.f;
+            if (n < D) part = fmaf(dx[i], x0r[i], part);
+        }
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            const float ds = rs_wave_sum(part);
+            const float s = sv[l];
+            part = 0.f;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int n = lane + 64 * i;
+                if (n < D) {
+                    float xl = x0r[i];
+#pragma unroll
+                    for (int t = 0; t < l; ++t) xl = x0r[i] * sv[t] + sbias[t * D + n] + xl;
+                    const float g = dx[i];
+                    accB[l][i] += g;
+                    accW[l][i] = fmaf(ds, xl, accW[l][i]);
+                    d0[i] = fmaf(g, s, d0[i]);
+                    const float gn = fmaf(ds, sw[l * D + n], g);
+                    dx[i] = gn;
+                    part = fmaf(gn, x0r[i], part);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            if (n < D) dx0[(long long)b * D + n] = d0[i] + dx[i];
+        }
+    }
+    __syncthreads();                     // every wave is done with w | bias
+    float* mine = sm + wv * 2 * L * D;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            if (n < D) { mine[l * D + n] = accW[l][i]; mine[L * D + l * D + n] = accB[l][i]; }
+        }
+    __syncthreads();
+    float* prow = partials + (long long)blockIdx.x * 2 * L * D;
+    for (int i = threadIdx.x; i < 2 * L * D; i += 256)
+        prow[i] = ((sm[i] + sm[2 * L * D + i]) + sm[4 * L * D + i]) + sm[6 * L * D + i];
+}
+
 // ---- NFM bi-interaction in the reference's form (model/NFM/NFM.py:42-44) ---------------------------
 // out[b,c] = 0.5 * ((sum_n e_n v_nc)^2 - sum_n e_n^2 v_nc^2), e = flattened (B, D) embeddings, v (D, K).
 constexpr int NFM_KMAX = 16;
@@ -441,6 +568,114 @@ __global__ __launch_bounds__(256) void nfm_bi_bwd_kernel(const float* __restrict
         for (int v = 0; v < nw; ++v) t += sm[v * D * K + i];
         prow[i] = t;
     }
+}
+
+// Register forms of the two NFM kernels for D <= 64*T: V sits in LDS once per workgroup, a lane's T elements of a
+// sample are loaded up front, and (backward) its T*KT dV accumulators stay in registers.  Same arithmetic and
+// summation orders as the kernels above.
+template <int T, int KT>
+__global__ __launch_bounds__(256) void nfm_bi_fwd_reg_kernel(const float* __restrict__ E, const float* __restrict__ V, int B,
+                                                             int D, int K, float* __restrict__ out,
+                                                             float* __restrict__ s_out) {
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < D * K; i += 256) sm[i] = V[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += gridDim.x * 4) {
+        float e[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            e[i] = n < D ? E[(long long)b * D + n] : 0.f;
+        }
+        float s[KT], q[KT];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) s[c] = q[c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            if (n < D) {
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    if (c < K) {
+                        const float v = sm[n * K + c];
+                        s[c] = fmaf(e[i], v, s[c]);
+                        q[c] = fmaf(e[i] * e[i], v * v, q[c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            if (c < K) {
+                const float sc = rs_wave_sum(s[c]), qc = rs_wave_sum(q[c]);
+                if (lane == 0) {
+                    out[(long long)b * K + c] = 0.5f * (sc * sc - qc);
+                    if (s_out) s_out[(long long)b * K + c] = sc;
+                }
+            }
+        }
+    }
+}
+
+template <int T, int KT>
+__global__ __launch_bounds__(256) void nfm_bi_bwd_reg_kernel(const float* __restrict__ E, const float* __restrict__ V,
+                                                             const float* __restrict__ s_in, const float* __restrict__ dout,
+                                                             int B, int D, int K, float* __restrict__ dE,
+                                                             float* __restrict__ partials) {
+    extern __shared__ float sm[];        // first V, at the end the four waves' accumulators [4][D*K]
+    for (int i = threadIdx.x; i < D * K; i += 256) sm[i] = V[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float acc[T][KT];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int c = 0; c < KT; ++c) acc[i][c] = 0.f;
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        float g[KT], s[KT], e[T];
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            g[c] = c < K ? dout[(long long)b * K + c] : 0.f;
+            s[c] = c < K ? s_in[(long long)b * K + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            e[i] = n < D ? E[(long long)b * D + n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            if (n < D) {
+                float de = 0.f;
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    if (c < K) {
+                        const float v = sm[n * K + c];
+                        de = fmaf(g[c], s[c] * v - e[i] * v * v, de);
+                        acc[i][c] = fmaf(g[c] * e[i], s[c] - e[i] * v, acc[i][c]);
+                    }
+                }
+                dE[(long long)b * D + n] = de;
+            }
+        }
+    }
+    __syncthreads();                     // every wave is done with V
+    float* mine = sm + wv * D * K;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int n = lane + 64 * i;
+        if (n < D) {
+#pragma unroll
+            for (int c = 0; c < KT; ++c)
+                if (c < K) mine[n * K + c] = acc[i][c];
+        }
+    }
+    __syncthreads();
+    float* prow = partials + (long long)blockIdx.x * D * K;
+    for (int i = threadIdx.x; i < D * K; i += 256)
+        prow[i] = ((sm[i] + sm[D * K + i]) + sm[2 * D * K + i]) + sm[3 * D * K + i];
 }
 
 // ---- AFM attention pooling (model/AFM/AFM.py:19-24, 36-42, 47-56) ----------------------------------
@@ -1190,6 +1425,41 @@ int afm_region_floats(int F, int d, int A, bool bwd) {
         default: break;                                                                            \
     }
 
+// Elements per lane (T) instantiated for the register forms of the cross-network kernels: smallest >= ceil(D/64).
+int dcn_reg_T(int D) {
+    const int need = rs_cdiv(D, 64);
+    const int opts[] = {2, 4, 7, 10, 13, 16};
+    for (int t : opts) if (t >= need) return t;
+    return 0;
+}
+#define RS_DCN_CASE(K, T, L) case (T) * 10 + (L): K(T, L); break;
+#define RS_DCN_ROW(K, T) RS_DCN_CASE(K, T, 1) RS_DCN_CASE(K, T, 2) RS_DCN_CASE(K, T, 3) RS_DCN_CASE(K, T, 4)
+#define RS_DCN_DISPATCH(K, T, L)                                                                   \
+    switch ((T) * 10 + (L)) {                                                                      \
+        RS_DCN_ROW(K, 2) RS_DCN_ROW(K, 4) RS_DCN_ROW(K, 7) RS_DCN_ROW(K, 10) RS_DCN_ROW(K, 13) RS_DCN_ROW(K, 16) \
+        default: break;                                                                            \
+    }
+
+int nfm_KT(int K) { return K <= 1 ? 1 : (K <= 2 ? 2 : (K <= 4 ? 4 : (K <= 8 ? 8 : 16))); }
+#define RS_NFM_CASE(K_, T, KT) case (T) * 100 + (KT): K_(T, KT); break;
+#define RS_NFM_FWD_ROW(K_, T) RS_NFM_CASE(K_, T, 1) RS_NFM_CASE(K_, T, 2) RS_NFM_CASE(K_, T, 4) RS_NFM_CASE(K_, T, 8) RS_NFM_CASE(K_, T, 16)
+#define RS_NFM_FWD_DISPATCH(K_, T, KT)                                                             \
+    switch ((T) * 100 + (KT)) {                                                                    \
+        RS_NFM_FWD_ROW(K_, 2) RS_NFM_FWD_ROW(K_, 4) RS_NFM_FWD_ROW(K_, 7) RS_NFM_FWD_ROW(K_, 10)   \
+        RS_NFM_FWD_ROW(K_, 13) RS_NFM_FWD_ROW(K_, 16)                                              \
+        default: break;                                                                            \
+    }
+// backward: T*KT accumulator registers per lane, instantiated up to 64
+#define RS_NFM_BWD_DISPATCH(K_, T, KT)                                                             \
+    switch ((T) * 100 + (KT)) {                                                                    \
+        RS_NFM_FWD_ROW(K_, 2) RS_NFM_FWD_ROW(K_, 4)                                                \
+        RS_NFM_CASE(K_, 7, 1) RS_NFM_CASE(K_, 7, 2) RS_NFM_CASE(K_, 7, 4) RS_NFM_CASE(K_, 7, 8)    \
+        RS_NFM_CASE(K_, 10, 1) RS_NFM_CASE(K_, 10, 2) RS_NFM_CASE(K_, 10, 4)                       \
+        RS_NFM_CASE(K_, 13, 1) RS_NFM_CASE(K_, 13, 2) RS_NFM_CASE(K_, 13, 4)                       \
+        RS_NFM_CASE(K_, 16, 1) RS_NFM_CASE(K_, 16, 2) RS_NFM_CASE(K_, 16, 4)                       \
+        default: break;                                                                            \
+    }
+
 }  // namespace
 
 extern "C" {
@@ -1245,7 +1515,8 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
     RS_CHECK_ARG(emb && dout && demb, "rs_pnn_inner_bwd: null argument");
     if (pnn_mfma_ok(F, d, emb)) {
         const int grid = pnn_mfma_grid(B);
-#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), 0, stream, emb, dout, B, F, demb)
+        const size_t blds = (size_t)4 * (F * (F - 1) / 2 + 1) * sizeof(float);
+#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), blds, stream, emb, dout, B, F, demb)
         RS_PNN_DISPATCH(RS_PNN_B)
 #undef RS_PNN_B
         RS_CHECK_LAUNCH("rs_pnn_inner_bwd");
@@ -1291,6 +1562,16 @@ int rs_dcn_cross_fwd(const float* x0, const float* w, const float* bias, int B, 
     RS_CHECK_ARG(B >= 0 && D > 0 && L > 0, "rs_dcn_cross_fwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(x0 && w && bias && out, "rs_dcn_cross_fwd: null argument");
+    const int T = dcn_reg_T(D);
+    if (T && L <= 4 && (size_t)2 * L * D * sizeof(float) <= LDS_LIMIT) {
+        const int grid = rs_cdiv(B, 4) < 1024 ? rs_cdiv(B, 4) : 1024;
+        const size_t rlds = (size_t)2 * L * D * sizeof(float);
+#define RS_DCN_F(TT, LL) hipLaunchKernelGGL((dcn_cross_fwd_reg_kernel<TT, LL>), dim3(grid), dim3(256), rlds, stream, x0, w, bias, B, D, out, S)
+        RS_DCN_DISPATCH(RS_DCN_F, T, L)
+#undef RS_DCN_F
+        RS_CHECK_LAUNCH("rs_dcn_cross_fwd");
+        return RS_OK;
+    }
     const size_t lds = (size_t)4 * D * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_dcn_cross_fwd: D=%d does not fit the LDS staging", D);
     hipLaunchKernelGGL(dcn_cross_fwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), lds, stream, x0, w, bias, B, D, L, out, S);
@@ -1306,6 +1587,20 @@ int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const f
     RS_CHECK_ARG(x0 && S && dout && w && bias && dx0 && partials, "rs_dcn_cross_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_dcn_cross_bwd: partials must have %d rows",
                  rs_interact_partial_rows(B));
+    const int T = dcn_reg_T(D);
+    if (T && L <= 4 && (size_t)8 * L * D * sizeof(float) <= LDS_BIG) {
+        const size_t rlds = (size_t)8 * L * D * sizeof(float);
+#define RS_DCN_B(TT, LL)                                                                                               \
+    do {                                                                                                               \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(dcn_cross_bwd_reg_kernel<TT, LL>)), "rs_dcn_cross_bwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL((dcn_cross_bwd_reg_kernel<TT, LL>), dim3(rows), dim3(256), rlds, stream, x0, S, dout, w, bias, B, D, \
+                           dx0, partials);                                                                             \
+    } while (0)
+        RS_DCN_DISPATCH(RS_DCN_B, T, L)
+#undef RS_DCN_B
+        RS_CHECK_LAUNCH("rs_dcn_cross_bwd");
+        return RS_OK;
+    }
     const size_t per_wave = (size_t)(2 * L + 2) * D * sizeof(float);
     RS_CHECK_ARG(per_wave <= LDS_BIG, "rs_dcn_cross_bwd: L=%d D=%d does not fit the LDS staging", L, D);
     const int nw = waves_for(per_wave);
@@ -1322,6 +1617,18 @@ int rs_nfm_bi_fwd(const float* E, const float* V, int B, int D, int K, float* ou
     RS_CHECK_ARG(B >= 0 && D > 0 && K > 0 && K <= NFM_KMAX, "rs_nfm_bi_fwd: bad sizes (hidden_dim <= %d)", NFM_KMAX);
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(E && V && out, "rs_nfm_bi_fwd: null argument");
+    {
+        const int T = dcn_reg_T(D), KT = nfm_KT(K);
+        const size_t rlds = (size_t)D * K * sizeof(float);
+        if (T && rlds <= LDS_LIMIT) {
+            const int grid = rs_cdiv(B, 4) < 1024 ? rs_cdiv(B, 4) : 1024;
+#define RS_NFM_FR(TT, KK) hipLaunchKernelGGL((nfm_bi_fwd_reg_kernel<TT, KK>), dim3(grid), dim3(256), rlds, stream, E, V, B, D, K, out, s_out)
+            RS_NFM_FWD_DISPATCH(RS_NFM_FR, T, KT)
+#undef RS_NFM_FR
+            RS_CHECK_LAUNCH("rs_nfm_bi_fwd");
+            return RS_OK;
+        }
+    }
 #define RS_NFM_F(KT) hipLaunchKernelGGL(nfm_bi_fwd_kernel<KT>, dim3(rs_cdiv(B, 4)), dim3(256), 0, stream, E, V, B, D, K, out, s_out)
     if (K <= 1) RS_NFM_F(1); else if (K <= 2) RS_NFM_F(2); else if (K <= 4) RS_NFM_F(4); else if (K <= 8) RS_NFM_F(8); else RS_NFM_F(16);
 #undef RS_NFM_F
@@ -1336,6 +1643,22 @@ int rs_nfm_bi_bwd(const float* E, const float* V, const float* s, const float* d
     RS_CHECK_ARG(E && V && s && dout && dE && partials, "rs_nfm_bi_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_nfm_bi_bwd: partials must have %d rows",
                  rs_interact_partial_rows(B));
+    {
+        const int T = dcn_reg_T(D), KT = nfm_KT(K);
+        const size_t rlds = (size_t)4 * D * K * sizeof(float);
+        if (T && T * KT <= 64 && rlds <= LDS_BIG) {
+#define RS_NFM_BR(TT, KK)                                                                                              \
+    do {                                                                                                               \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(nfm_bi_bwd_reg_kernel<TT, KK>)), "rs_nfm_bi_bwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL((nfm_bi_bwd_reg_kernel<TT, KK>), dim3(rows), dim3(256), rlds, stream, E, V, s, dout, B, D, K, dE, \
+                           partials);                                                                                  \
+    } while (0)
+            RS_NFM_BWD_DISPATCH(RS_NFM_BR, T, KT)
+#undef RS_NFM_BR
+            RS_CHECK_LAUNCH("rs_nfm_bi_bwd");
+            return RS_OK;
+        }
+    }
     const size_t per_wave = (size_t)D * K * sizeof(float);
     RS_CHECK_ARG(per_wave <= LDS_BIG, "rs_nfm_bi_bwd: D*K=%d does not fit the LDS staging", D * K);
     const int nw = waves_for(per_wave);

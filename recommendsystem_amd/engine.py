@@ -123,7 +123,8 @@ class FusedTrainer:
         self._alloc_state()
         self._plans: Dict[int, ops.SparsePlan] = {}
         self.use_graph = use_graph
-        self.overlap = bool(overlap)
+        # 1/True: index sort and weight-gradient GEMMs on side streams; 2: only the index sort
+        self.overlap = int(overlap)
         self._sort_can_fork = True
         self.side_w = torch.cuda.Stream(device=dev)
         self.side_sort = torch.cuda.Stream(device=dev)
@@ -310,10 +311,10 @@ class FusedTrainer:
         B = idx.shape[1]
         plan = self.plan(B)
         main = torch.cuda.current_stream()
-        overlap = self.overlap
+        overlap = self.overlap == 1
         keep = []                    # intermediates read on side streams stay alive until the join
         # The index sort needs only the batch: it runs beside the forward pass.
-        fork_sort = overlap and self._sort_can_fork
+        fork_sort = bool(self.overlap) and self._sort_can_fork
         if fork_sort:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
