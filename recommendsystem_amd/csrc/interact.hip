@@ -268,6 +268,34 @@ __global__ __launch_bounds__(256) void pnn_outer_fwd_kernel(const float* __restr
     }
 }
 
+// d = 16: index arithmetic by shifts; a wave writes one whole 16x16 block (1 KB contiguous) per step.
+__global__ __launch_bounds__(256) void pnn_outer_fwd16_kernel(const float* __restrict__ emb, int B, int F,
+                                                              float* __restrict__ out) {
+    extern __shared__ float sm[];
+    const int fd = F * 16, P = F * (F - 1) / 2;
+    float* e = sm;
+    int* tab = reinterpret_cast<int*>(sm + fd);
+    const int b = blockIdx.x;
+    const float* src = emb + (long long)b * fd;
+    for (int i = threadIdx.x; i < fd; i += 256) e[i] = src[i];
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i, j;
+        pair_decode(p, F, &i, &j);
+        tab[p] = i | (j << 16);
+    }
+    __syncthreads();
+    float4* o = reinterpret_cast<float4*>(out + (long long)b * P * 256);
+    const int total = P * 64;
+#pragma unroll 4
+    for (int q = threadIdx.x; q < total; q += 256) {
+        const int p = q >> 6, a = (q >> 2) & 15, c4 = q & 3;
+        const int ij = tab[p], i = ij & 0xffff, j = ij >> 16;
+        const float ea = e[i * 16 + a];
+        const float4 ej = *reinterpret_cast<const float4*>(e + j * 16 + 4 * c4);
+        o[q] = make_float4(ea * ej.x, ea * ej.y, ea * ej.z, ea * ej.w);
+    }
+}
+
 // demb[b,f,k] = sum_{j>f} sum_c dO[p(f,j), k, c] e_j[c] + sum_{i<f} sum_a dO[p(i,f), a, k] e_i[a]
 __global__ __launch_bounds__(256) void pnn_outer_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
                                                             int B, int F, int d, float* __restrict__ demb) {
@@ -292,6 +320,78 @@ __global__ __launch_bounds__(256) void pnn_outer_bwd_kernel(const float* __restr
         }
         demb[(long long)b * fd + idx] = acc;
     }
+}
+
+// The same gradient for d = 16 with every dO element read once through full 64-byte requests.  A 16x16 block of dO
+// is held by 16 lanes as 4x4 sub-tiles (lane = (group, ta, tc): rows 4ta.., columns 4tc..), four blocks (i, j..j+3)
+// per wave and step.  Row sums (for e_i) accumulate in registers over j and are reduced across lanes once per i;
+// column sums (for e_j) are reduced over ta with two shuffle steps and added to the wave's own LDS accumulator.
+// The four waves of the workgroup (rows i = wave, wave + 4, ...) are combined in fixed order at the end.
+__global__ __launch_bounds__(256) void pnn_outer_bwd16_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                              int B, int F, float* __restrict__ demb) {
+    extern __shared__ float sm[];
+    const int fd = F * 16, P = F * (F - 1) / 2;
+    float* e = sm;                    // [F*16]
+    float* rowres = e + fd;           // [F*16]
+    float* colacc = rowres + fd;      // [4][F*16]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float* src = emb + (long long)b * fd;
+    for (int i = threadIdx.x; i < fd; i += 256) { e[i] = src[i]; rowres[i] = 0.f; }
+    for (int i = threadIdx.x; i < 4 * fd; i += 256) colacc[i] = 0.f;
+    __syncthreads();
+    const int tc = lane & 3, ta = (lane >> 2) & 3, gq = lane >> 4;
+    const float* gbase = dout + (long long)b * P * 256;
+    float* myc = colacc + wv * fd;
+    for (int i = wv; i < F - 1; i += 4) {
+        float ei[4], racc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ei[r] = e[i * 16 + 4 * ta + r]; racc[r] = 0.f; }
+        const int p0 = pair_start(i, F) - i - 1;           // block of pair (i, j) = p0 + j
+        for (int j0 = i + 1; j0 < F; j0 += 4) {
+            const int j = j0 + gq;
+            const bool on = j < F;
+            float4 v[4];
+            float4 ej = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on) {
+                const float* blk = gbase + (long long)(p0 + j) * 256 + 4 * tc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const float4*>(blk + (4 * ta + r) * 16);
+                ej = *reinterpret_cast<const float4*>(e + j * 16 + 4 * tc);
+            }
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                racc[r] = fmaf(v[r].x, ej.x, racc[r]); racc[r] = fmaf(v[r].y, ej.y, racc[r]);
+                racc[r] = fmaf(v[r].z, ej.z, racc[r]); racc[r] = fmaf(v[r].w, ej.w, racc[r]);
+                cp.x = fmaf(v[r].x, ei[r], cp.x); cp.y = fmaf(v[r].y, ei[r], cp.y);
+                cp.z = fmaf(v[r].z, ei[r], cp.z); cp.w = fmaf(v[r].w, ei[r], cp.w);
+            }
+#pragma unroll
+            for (int o = 4; o <= 8; o <<= 1) {
+                cp.x += __shfl_xor(cp.x, o, 64); cp.y += __shfl_xor(cp.y, o, 64);
+                cp.z += __shfl_xor(cp.z, o, 64); cp.w += __shfl_xor(cp.w, o, 64);
+            }
+            if (on && ta == 0) {
+                float4* dst = reinterpret_cast<float4*>(myc + j * 16 + 4 * tc);
+                float4 t = *dst;
+                t.x += cp.x; t.y += cp.y; t.z += cp.z; t.w += cp.w;
+                *dst = t;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = racc[r];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            if (tc == 0 && gq == 0) rowres[i * 16 + 4 * ta + r] = t;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < fd; i += 256)
+        demb[(long long)b * fd + i] = rowres[i] + (((colacc[i] + colacc[fd + i]) + colacc[2 * fd + i]) + colacc[3 * fd + i]);
 }
 
 // ---- DCN cross network (model/DCN/DCN.py:48-52 in its intended (B, D) shape) -----------------------
@@ -1538,7 +1638,9 @@ int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, hipStrea
     RS_CHECK_ARG((long long)P * d * d < (1ll << 31), "rs_pnn_outer_fwd: output row too long");
     const size_t lds = (size_t)(F * d + P) * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_outer_fwd: F=%d d=%d does not fit the LDS staging", F, d);
-    if (d % 4 == 0) hipLaunchKernelGGL(pnn_outer_fwd_kernel<4>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out);
+    if (d == 16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+        hipLaunchKernelGGL(pnn_outer_fwd16_kernel, dim3(B), dim3(256), lds, stream, emb, B, F, out);
+    else if (d % 4 == 0) hipLaunchKernelGGL(pnn_outer_fwd_kernel<4>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out);
     else hipLaunchKernelGGL(pnn_outer_fwd_kernel<1>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out);
     RS_CHECK_LAUNCH("rs_pnn_outer_fwd");
     return RS_OK;
@@ -1548,6 +1650,12 @@ int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, f
     RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_outer_bwd: bad sizes");
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && dout && demb, "rs_pnn_outer_bwd: null argument");
+    if (d == 16 && (size_t)6 * F * 16 * sizeof(float) <= LDS_LIMIT && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) {
+        hipLaunchKernelGGL(pnn_outer_bwd16_kernel, dim3(B), dim3(256), (size_t)6 * F * 16 * sizeof(float), stream, emb, dout, B,
+                           F, demb);
+        RS_CHECK_LAUNCH("rs_pnn_outer_bwd");
+        return RS_OK;
+    }
     const size_t lds = (size_t)F * d * sizeof(float);
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_outer_bwd: F*d=%d does not fit the LDS staging", F * d);
     hipLaunchKernelGGL(pnn_outer_bwd_kernel, dim3(B), dim3(256), lds, stream, emb, dout, B, F, d, demb);
