@@ -187,6 +187,12 @@ int rs_ffm_bwd_rows(const int* plan, const int64_t* idx, const int64_t* row_offs
                     const float* dout, int B, int F, int cap, int d, float* rowgrad, float* chunk_part,
                     float* norm_partials, rs_stream_t stream);
 
+/* FFM on rows already gathered by the row-sharded exchange: G [B, F, F*d] with G[b, i, :] the field-aware row of
+ * sample b's value in field i (same arithmetic as rs_ffm_fwd, FFM.py:43-62); dG [B, F, F*d] is the gradient with
+ * respect to the gathered rows, reduced per distinct key by rs_sparse_bwd_reduce_wide. */
+int rs_ffm_rows_fwd(const float* G, int B, int F, int d, float* out, rs_stream_t stream);
+int rs_ffm_rows_bwd(const float* G, const float* dout, int B, int F, int d, float* dG, rs_stream_t stream);
+
 /* ---- K3: deterministic sparse embedding backward + optimizer (BaseModel.py:141-150) ---------- */
 /* plan: int32 scratch of rs_sort_plan_ints(F, cap) elements.  Per field, `nsrc` sub-lists of keys are
  * concatenated (a columnar [F,B] batch is nsrc=1, sub_off[f]=f*B, sub_cnt[f]=B, pay_base[f]=f,
@@ -206,6 +212,13 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
                          const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                          float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
                          rs_stream_t stream);
+/* The same reduction for rows of W floats (W % 4 == 0, W <= 1024; field-aware FFM rows on the row-sharded path):
+ * rowgrad[f, s, :] = sum of gout[sorted_src[q], :] over the entries of segment s, in ascending order; chunk_part
+ * [F, cap, W] is scratch; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.  The plan's window L
+ * must be <= 64.  (BaseModel.py:141-150: the gradient of an nn.Embedding row is the sum over its occurrences.) */
+int rs_sparse_bwd_wide_num_partials(int F, int cap);
+int rs_sparse_bwd_reduce_wide(const int* plan, int F, int cap, int W, const float* gout, float* rowgrad, float* chunk_part,
+                              float* norm_partials, rs_stream_t stream);
 /* Optimizer step on the touched rows only (hyper: 8 floats, see rs_opt_prepare; scal[1] = clip coefficient). */
 int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                      float* table, float* m, float* v, float* table1, float* m1, float* v1, const float* hyper,

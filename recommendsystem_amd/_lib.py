@@ -83,6 +83,9 @@ _SIGS = {
     "rs_afm_bwd": [c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, c_stream],
     "rs_ffm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, I, I, I, c_f32p, c_i32p, c_stream],
     "rs_ffm_bwd": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_stream],
+    "rs_ffm_rows_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_ffm_rows_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_sparse_bwd_reduce_wide": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_ffm_bwd_rows": [c_i32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
 }
 # entry points that do not follow the "returns int status" convention: name -> (restype, argtypes)
@@ -103,6 +106,7 @@ _PLAIN = {
     "rs_act_bwd_num_partials": (I, [L]),
     "rs_interact_partial_rows": (I, [I]),
     "rs_ffm_bwd_num_partials": (I, [I, I]),
+    "rs_sparse_bwd_wide_num_partials": (I, [I, I]),
 }
 
 _lib = None

@@ -1334,6 +1334,62 @@ __global__ __launch_bounds__(256) void ffm_fwd_vec_kernel(const int64_t* __restr
     }
 }
 
+// FFM on rows that have already been gathered (the row-sharded path): G [B, F, F*d], G[b, i, :] = the field-aware
+// row of sample b's value in field i.  out[b] = sum_{i<j} <G[b,i,j*d..], G[b,j,i*d..]>; the gradient with respect to
+// the gathered rows is dG[b,i,j*d..] = dout[b] * G[b,j,i*d..] for j != i and zero for the own-field block.
+template <int LP>
+__global__ __launch_bounds__(256) void ffm_rows_fwd_kernel(const float* __restrict__ G, int B, int F, float* __restrict__ out) {
+    extern __shared__ float sm[];
+    constexpr int d = 4 * LP, PPW = 64 / LP;
+    const int P = F * (F - 1) / 2;
+    int* tab = reinterpret_cast<int*>(sm);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i, j;
+        pair_decode(p, F, &i, &j);
+        tab[p] = i | (j << 16);
+    }
+    __syncthreads();
+    const int sub = lane % LP, pl = lane / LP;
+    const long long fd = (long long)F * d;
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        const float* g = G + (long long)b * F * fd;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int p0 = 0; p0 < P; p0 += PPW) {
+            const int p = p0 + pl;
+            if (p < P) {
+                const int ij = tab[p], i = ij & 0xffff, j = ij >> 16;
+                const float4 x = *reinterpret_cast<const float4*>(g + i * fd + j * d + 4 * sub);
+                const float4 y = *reinterpret_cast<const float4*>(g + j * fd + i * d + 4 * sub);
+                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+            }
+        }
+        acc = rs_wave_sum(acc);
+        if (lane == 0) out[b] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void ffm_rows_bwd_kernel(const float* __restrict__ G, const float* __restrict__ dout, int B,
+                                                           int F, int d, float* __restrict__ dG) {
+    const int fdv = F * d / 4;                 // float4s per row
+    const long long total = (long long)B * F * fdv;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+        const int c4 = (int)(q % fdv);
+        const long long bi = q / fdv;
+        const int i = (int)(bi % F);
+        const long long b = bi / F;
+        const int c = 4 * c4, j = c / d, k = c - j * d;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j != i) {
+            const float g = dout[b];
+            const float4 t = *reinterpret_cast<const float4*>(G + ((b * F + j) * (long long)F + i) * d + k);
+            v = make_float4(g * t.x, g * t.y, g * t.z, g * t.w);
+        }
+        reinterpret_cast<float4*>(dG)[q] = v;
+    }
+}
+
 // Gradients of the distinct table rows of a batch, compact: rowgrad[f, s, :] (F*d floats) for segment s of field f
 // of the sorted batch (see sparse.hip), in the layout the touched-rows optimizer kernels read, plus sum-of-squares
 // partials for the global gradient norm.
@@ -1907,6 +1963,40 @@ int rs_ffm_bwd(const int* plan, const int64_t* idx, const int64_t* row_offset, c
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     hipLaunchKernelGGL(ffm_bwd_kernel, dim3(B, F), dim3(256), 0, stream, pv, idx, row_offset, vocab, T, dout, B, F, cap, d, dT);
     RS_CHECK_LAUNCH("rs_ffm_bwd");
+    return RS_OK;
+}
+
+// FFM term and its gradient on gathered rows G [B, F, F*d] (see ffm_rows_fwd_kernel); d in {4, 8, 16, 32, 64}.
+int rs_ffm_rows_fwd(const float* G, int B, int F, int d, float* out, hipStream_t stream) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && F < 32768, "rs_ffm_rows_fwd: bad sizes");
+    if (B == 0) return RS_OK;
+    RS_CHECK_ARG(G && out && (reinterpret_cast<uintptr_t>(G) & 15) == 0, "rs_ffm_rows_fwd: null or unaligned argument");
+    const int LP = d / 4;
+    RS_CHECK_ARG(d % 4 == 0 && LP >= 1 && LP <= 16 && (LP & (LP - 1)) == 0, "rs_ffm_rows_fwd: embedding_dim %d not in {4,8,16,32,64}", d);
+    const size_t lds = (size_t)(F * (F - 1) / 2) * sizeof(int);
+    RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_ffm_rows_fwd: F=%d does not fit the LDS pair table", F);
+    const int grid = rs_cdiv(B, 4) < 4096 ? rs_cdiv(B, 4) : 4096;
+#define RS_FFM_R(L) hipLaunchKernelGGL(ffm_rows_fwd_kernel<L>, dim3(grid), dim3(256), lds, stream, G, B, F, out)
+    switch (LP) {
+        case 1: RS_FFM_R(1); break;
+        case 2: RS_FFM_R(2); break;
+        case 4: RS_FFM_R(4); break;
+        case 8: RS_FFM_R(8); break;
+        default: RS_FFM_R(16); break;
+    }
+#undef RS_FFM_R
+    RS_CHECK_LAUNCH("rs_ffm_rows_fwd");
+    return RS_OK;
+}
+
+int rs_ffm_rows_bwd(const float* G, const float* dout, int B, int F, int d, float* dG, hipStream_t stream) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && d > 0 && d % 4 == 0, "rs_ffm_rows_bwd: bad sizes");
+    if (B == 0) return RS_OK;
+    RS_CHECK_ARG(G && dout && dG && ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(dG)) & 15) == 0,
+                 "rs_ffm_rows_bwd: null or unaligned argument");
+    hipLaunchKernelGGL(ffm_rows_bwd_kernel, dim3(flat_blocks((long long)B * F * F * d / 4)), dim3(256), 0, stream, G, dout, B, F,
+                       d, dG);
+    RS_CHECK_LAUNCH("rs_ffm_rows_bwd");
     return RS_OK;
 }
 

@@ -197,8 +197,9 @@ __global__ void shard_counts_kernel(const long long* __restrict__ recv_idx, int 
     }
 }
 
+// C lanes per row, 256 / C rows per workgroup: rows of up to 1024 floats (field-aware FFM rows) take a whole workgroup.
 int lanes(int d, int* VEC, int* C) {
-    if (d % 4 == 0 && d / 4 <= 64) { *VEC = 4; *C = d / 4; return 0; }
+    if (d % 4 == 0 && d / 4 <= 256) { *VEC = 4; *C = d / 4; return 0; }
     if (d <= 64) { *VEC = 1; *C = d; return 0; }
     return -1;
 }

@@ -341,6 +341,71 @@ __global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Segmented reduction for wide rows (W floats, W % 4 == 0, W <= 1024: one float4 per thread of a 256-thread
+// workgroup), used where a lane group per entry does not fit a wave (field-aware FFM rows on the row-sharded path).
+// Phase 1: one workgroup per chunk of the plan adds the chunk's gradient rows gout[sorted_src[q], :] in ascending
+// order; the sum goes straight to rowgrad when the row has a single chunk, else to chunk_part[f, chunk, :].
+// Phase 2 adds the chunk sums of multi-chunk rows in chunk order.  Both leave ||g||^2 partials.
+__global__ __launch_bounds__(256) void wide_chunk_reduce_kernel(PlanView pv, int cap, int W, const float* __restrict__ gout,
+                                                                float* __restrict__ rowgrad, float* __restrict__ chunk_part,
+                                                                float* __restrict__ norm_partials) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const int nchunk = pv.counts[f * 4 + 1];
+    const int* sfc = pv.seg_first_chunk + (long long)f * (cap + 1);
+    const int* cst = pv.chunk_start + (long long)f * (cap + 1);
+    const int* ssrc = pv.sorted_src + (long long)f * cap;
+    const int* eseg = pv.entry_seg + (long long)f * cap;
+    const int c = 4 * threadIdx.x;
+    const bool has = c < W;
+    float nsq = 0.f;
+    for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const int beg = cst[ch], end = cst[ch + 1];
+        const int seg = eseg[beg];
+        const bool single = sfc[seg + 1] - sfc[seg] == 1;
+        if (has) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = beg; q < end; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(gout + (long long)ssrc[q] * W + c);
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+            float* dst = single ? rowgrad + ((long long)f * cap + seg) * W : chunk_part + ((long long)f * cap + ch) * W;
+            *reinterpret_cast<float4*>(dst + c) = acc;
+            if (single) nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        }
+    }
+    const float tot = rs_block_sum<256>(nsq, red);
+    if (threadIdx.x == 0) norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void wide_finish_kernel(PlanView pv, int cap, int W, float* __restrict__ rowgrad,
+                                                          const float* __restrict__ chunk_part,
+                                                          float* __restrict__ norm_partials) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const int nseg = pv.counts[f * 4 + 2];
+    const int* sfc = pv.seg_first_chunk + (long long)f * (cap + 1);
+    const int c = 4 * threadIdx.x;
+    const bool has = c < W;
+    float nsq = 0.f;
+    for (int s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const int c0 = sfc[s], c1 = sfc[s + 1];
+        if (c1 - c0 < 2 || !has) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ch = c0; ch < c1; ++ch) {
+            const float4 t = *reinterpret_cast<const float4*>(chunk_part + ((long long)f * cap + ch) * W + c);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        *reinterpret_cast<float4*>(rowgrad + ((long long)f * cap + s) * W + c) = acc;
+        nsq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+    }
+    const float tot = rs_block_sum<256>(nsq, red);
+    if (threadIdx.x == 0) norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+constexpr int WIDE_CHUNK_GROUPS = 1024, WIDE_FINISH_GROUPS = 64;
+
+// -------------------------------------------------------------------------------------------
 // hyper[]: 0 lr, 1 beta1, 2 beta2, 3 eps, 4 weight_decay, 5 step_size (= lr / (1-beta1^t)),
 //          6 sqrt(1-beta2^t), 7 reserved.  scal[]: 0 total grad norm, 1 clip coefficient.
 enum { OPT_SGD = 0, OPT_ADAM = 1, OPT_ADAMW = 2, OPT_ADAGRAD = 3 };
@@ -637,6 +702,29 @@ static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, in
     a.counts = pv.counts;
     a.F = F; a.cap = cap; a.d = d;
     return lanes_wide(d, VEC, &a.C);
+}
+
+// Wide-row form of rs_sparse_bwd_reduce: gout [*, W] gradient rows indexed by the plan's sorted_src; rowgrad and
+// chunk_part (scratch) are [F, cap, W]; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.
+// W % 4 == 0, W <= 1024.
+int rs_sparse_bwd_wide_num_partials(int F, int cap) {
+    return F * ((cap < WIDE_CHUNK_GROUPS ? cap : WIDE_CHUNK_GROUPS) + (cap < WIDE_FINISH_GROUPS ? cap : WIDE_FINISH_GROUPS));
+}
+
+int rs_sparse_bwd_reduce_wide(const int* plan, int F, int cap, int W, const float* gout, float* rowgrad, float* chunk_part,
+                              float* norm_partials, hipStream_t stream) {
+    RS_CHECK_ARG(plan && gout && rowgrad && chunk_part && norm_partials, "rs_sparse_bwd_reduce_wide: null argument");
+    RS_CHECK_ARG(F > 0 && cap > 0 && W > 0 && W % 4 == 0 && W <= 1024, "rs_sparse_bwd_reduce_wide: row width %d not in 4..1024 step 4", W);
+    RS_CHECK_ARG(((reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(rowgrad) |
+                   reinterpret_cast<uintptr_t>(chunk_part)) & 15) == 0, "rs_sparse_bwd_reduce_wide: buffers must be 16-byte aligned");
+    const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
+    const int g1 = cap < WIDE_CHUNK_GROUPS ? cap : WIDE_CHUNK_GROUPS, g2 = cap < WIDE_FINISH_GROUPS ? cap : WIDE_FINISH_GROUPS;
+    hipLaunchKernelGGL(wide_chunk_reduce_kernel, dim3(g1, F), dim3(256), 0, stream, pv, cap, W, gout, rowgrad, chunk_part,
+                       norm_partials);
+    hipLaunchKernelGGL(wide_finish_kernel, dim3(g2, F), dim3(256), 0, stream, pv, cap, W, rowgrad, chunk_part,
+                       norm_partials + (size_t)F * g1);
+    RS_CHECK_LAUNCH("rs_sparse_bwd_reduce_wide");
+    return RS_OK;
 }
 
 // Optimizer step on the touched rows only.  opt: 0 SGD, 1 Adam, 2 AdamW, 3 Adagrad (state in m).

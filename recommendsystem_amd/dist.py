@@ -25,7 +25,7 @@ from . import ops
 from ._lib import RSError, call, ptr, stream
 from .engine import FusedTrainer, N_DENSE_PARTIALS
 from .sparse_trainer import SparseTrainer
-from .ops import FieldLayout, SparsePlan
+from .ops import FieldLayout, SparsePlan, WidePlan
 
 
 # -------------------------------------------------------------------------------------------------
@@ -236,6 +236,47 @@ class HipShardKernels:
     @property
     def n_own_partials(self):
         return self.plan_own.n_partials
+
+
+class HipShardKernelsWide(HipShardKernels):
+    """The same device side for rows of W floats (field-aware FFM rows: W = F*d up to 1024), where a row takes a whole
+    workgroup instead of a lane group: wide-row segmented reductions on both the requester and the owner side."""
+
+    def __init__(self, spec: ShardSpec, B: int, W: int, cap_b: int, device):
+        self.spec, self.B, self.d, self.cap_b = spec, B, W, cap_b
+        self.with_emb, self.with_lr = True, False
+        self.F = len(spec.vocab)
+        self.layout_req = FieldLayout(spec.vocab, device)
+        self.layout_own = FieldLayout(spec.local_vocab, device)
+        self.plan_req = WidePlan(self.layout_req, cap=B, W=W)
+        self.plan_own = WidePlan(self.layout_own, cap=spec.N * cap_b, W=W)
+        N, F = spec.N, self.F
+        sf = torch.arange(N * F, dtype=torch.int32, device=device)
+        self.sub_off = sf * (cap_b + 1) + 1
+        self.pay_base = sf * cap_b
+        self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
+        self.scratch_partials = torch.zeros(self.plan_req.n_partials_wide, dtype=torch.float32, device=device)
+
+    def reduce_local(self, gout, dfm, S, emb, dlr):
+        self.plan_req.reduce_wide(self.scratch_partials, gout)
+
+    def pack(self, route, grads, grads1):
+        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d,
+             ptr(self.plan_req.rowgrad_wide), None, ptr(grads), None, stream())
+
+    def merge(self, recv_idx, grads, grads1, partials):
+        N = self.spec.N
+        call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
+        self.plan_own.sort_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
+                                 max_entries=N * self.cap_b)
+        self.plan_own.reduce_wide(partials, grads.view(-1, self.d))
+
+    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1):
+        self.plan_own.update_wide(opt, hyper, scal, table, m, v)
+
+    @property
+    def n_own_partials(self):
+        return self.plan_own.n_partials_wide
 
 
 # -------------------------------------------------------------------------------------------------
@@ -480,6 +521,13 @@ class _ShardedLookups:
         ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None)
         return out
 
+    def ffm_rows(self, idx, holder):
+        st, ex = self.t._sharded(holder, "ffm", idx.shape[1])
+        F, B = idx.shape
+        out = torch.empty((B, F, holder.dim), dtype=torch.float32, device=idx.device)
+        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None)
+        return out
+
     def lr_terms(self, idx, holder):
         st, ex = self.t._sharded(holder, "lr", idx.shape[1])
         F, B = idx.shape
@@ -493,7 +541,8 @@ class DistributedSparseTrainer(SparseTrainer):
     the fused engine does not schedule (PNN, NFM, AFM, DCN, DeepCrossing, ...).  Same protocol as DistributedTrainer:
     per looked-up table three all-to-alls (distinct keys out, rows back, one gradient per distinct key out), one
     all-reduce of the flat dense gradient with the tables' ||g||^2 riding behind it, mean loss over the N*B samples.
-    Every rank must build the same model from the same seed.  FFM's field-aware rows are not exchanged yet."""
+    Every rank must build the same model from the same seed.  FFM's field-aware rows (F*d floats each) travel the same
+    way through the wide-row kernels (HipShardKernelsWide); the FFM term is then evaluated on the gathered rows."""
 
     def __init__(self, model, group=None, stage_cpu: bool = False, bucket_slack: float = 1.5, **kw):
         if kw.pop("use_graph", False):
@@ -521,8 +570,11 @@ class DistributedSparseTrainer(SparseTrainer):
         if ex is None:
             spec = st["spec"]
             cap_b = spec.bucket_capacity(B, slack=self.bucket_slack)
-            emb = kind == "emb"
-            k = HipShardKernels(spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
+            emb = kind != "lr"
+            if kind == "ffm":
+                k = HipShardKernelsWide(spec, B, holder.dim, cap_b, self.device)
+            else:
+                k = HipShardKernels(spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
             ex = ShardedExchange(k, self.comm, spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
             ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
             st["ex"][B] = ex
@@ -535,8 +587,6 @@ class DistributedSparseTrainer(SparseTrainer):
             g = rec["out"].grad
             if g is None:
                 continue
-            if rec["kind"] == "ffm":
-                raise RSError("DistributedSparseTrainer: FFM's field-aware rows are not row-sharded yet")
             if id(rec["holder"]) in seen:
                 raise RSError("DistributedSparseTrainer: a table was looked up twice in one forward pass")
             seen.add(id(rec["holder"]))
@@ -544,6 +594,10 @@ class DistributedSparseTrainer(SparseTrainer):
             st, ex = self._sharded(rec["holder"], rec["kind"], B)
             if rec["kind"] == "emb":
                 ex.backward(g.contiguous().view(B * ex.F, ex.d), None, None, None, None, ex.own_partials)
+            elif rec["kind"] == "ffm":
+                d = rec["holder"].dim // ex.F
+                dG = ops.ffm_rows_bwd(rec["rows"], g.contiguous().view(B), d)
+                ex.backward(dG.view(B * ex.F, ex.d), None, None, None, None, ex.own_partials)
             else:
                 ex.backward(None, None, None, None, g.contiguous().view(B), ex.own_partials)
             jobs.append((st, ex))
@@ -560,7 +614,7 @@ class DistributedSparseTrainer(SparseTrainer):
         ops.clip_and_prepare(P, self.max_norm, self.scal, self.step_count, self.hyper)
         ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
         for st, ex in jobs:
-            if st["kind"] == "emb":
+            if st["kind"] != "lr":
                 ex.k.update(self.opt, self.hyper, self.scal, st["shard"], st["m"], st["v"], None, None, None)
             else:
                 ex.k.update(self.opt, self.hyper, self.scal, None, None, None, st["shard"], st["m"], st["v"])

@@ -210,6 +210,11 @@ class FieldAwareTables(nn.Module):
             raise RSError("FieldAwareTables: the batch must be on the device")
         from .functional import TableCapture
         cap = TableCapture.active
+        if cap is not None and cap.provider is not None:
+            G = cap.provider.ffm_rows(idx, self._tab)          # [B, F, F*d] through the row-sharded exchange
+            out = cap.record("ffm", self._tab, idx, ops.ffm_rows_fwd(G, self.emb_dim))
+            cap.records[-1]["rows"] = G
+            return out.view(-1, 1)
         if cap is not None:
             T = self._tab.stacked_for(self._tab.weights())
             return cap.record("ffm", self._tab, idx, ops.ffm_fwd(idx, self._tab.layout, T)).view(-1, 1)

@@ -748,6 +748,56 @@ def ffm_bwd(plan: "SparsePlan", idx: torch.Tensor, T: torch.Tensor, dout: torch.
     return dT
 
 
+class WidePlan(SparsePlan):
+    """Sort plan + reduction buffers for gradient rows of W floats (W % 4 == 0, W <= 1024): the wide-row form of
+    SparsePlan.reduce / update used by the row-sharded exchange of field-aware FFM rows."""
+
+    def __init__(self, layout: FieldLayout, cap: int, W: int, device=None):
+        super().__init__(layout, cap, 1, with_lr=False, device=device)
+        if W % 4 or W > 1024:
+            raise RSError(f"wide rows: width {W} not in 4..1024 step 4")
+        if self.CHUNK > 64:
+            raise RSError("wide rows: plan window exceeds 64 entries")
+        self.width = int(W)
+        dev = device or layout.device
+        self.rowgrad_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
+        self.chunk_part_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
+        self.n_partials_wide = _lib.lib().rs_sparse_bwd_wide_num_partials(self.F, self.cap)
+
+    def reduce_wide(self, norm_partials: torch.Tensor, gout: torch.Tensor):
+        _chk(gout, torch.float32, "gout")
+        if gout.shape[-1] != self.width:
+            raise RSError("wide rows: gradient rows have the wrong width")
+        if norm_partials.numel() < self.n_partials_wide:
+            raise RSError("wide rows: norm_partials too small")
+        call("rs_sparse_bwd_reduce_wide", ptr(self.plan), self.F, self.cap, self.width, ptr(gout), ptr(self.rowgrad_wide),
+             ptr(self.chunk_part_wide), ptr(norm_partials), stream())
+
+    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None):
+        call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.width, OPT_CODES[opt], ptr(self.rowgrad_wide),
+             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal), stream())
+
+
+def ffm_rows_fwd(G: torch.Tensor, d: int) -> torch.Tensor:
+    """G [B, F, F*d] gathered field-aware rows -> out [B]."""
+    _chk(G, torch.float32, "G")
+    B, Fn, W = G.shape
+    if W != Fn * d:
+        raise RSError("ffm_rows_fwd: rows must be F*d wide")
+    out = torch.empty((B,), dtype=torch.float32, device=G.device)
+    call("rs_ffm_rows_fwd", ptr(G), B, Fn, d, ptr(out), stream())
+    return out
+
+
+def ffm_rows_bwd(G: torch.Tensor, dout: torch.Tensor, d: int) -> torch.Tensor:
+    """Gradient with respect to the gathered rows, [B, F, F*d]."""
+    B, Fn, W = G.shape
+    _chk(dout, torch.float32, "dout", (B,))
+    dG = torch.empty_like(G)
+    call("rs_ffm_rows_bwd", ptr(G), ptr(dout), B, Fn, d, ptr(dG), stream())
+    return dG
+
+
 class FFMPlan(SparsePlan):
     """Sort plan of a batch plus the compact buffer of field-aware row gradients (rows of F*d floats)."""
 

@@ -152,12 +152,14 @@ def build_gpu_model(kind, optimizer, batch):
         m = models.NFM(rec, 1e-2, 0, hidden_dim=4, **hid, **kw)
     elif kind == "afm":
         m = models.AFM(rec, 1e-2, 0, attention_dim=4, **kw)
+    elif kind == "ffm":
+        m = models.FFM(rec, 1e-2, 0, **kw)
     else:
         raise ValueError(kind)
     # larger initial rows than the reference's 1e-4 so that every term of the gradient matters
     with torch.no_grad():
         for n, p in m.named_parameters():
-            if p.dim() == 2 and p.shape[0] in vocab and "embedded" in n:
+            if p.dim() == 2 and p.shape[0] in vocab and ("embedded" in n or "tables" in n):
                 p[1:].normal_(0, 0.05)
             if n == "v" or n.startswith("cross."):
                 p.mul_(0.2)

@@ -50,7 +50,8 @@ def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, graph, tmp_path
         torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
 
 
-@pytest.mark.parametrize("kind,optimizer", [("pnn", "Adam"), ("dcn", "SGD"), ("nfm", "Adagrad"), ("afm", "AdamW")])
+@pytest.mark.parametrize("kind,optimizer", [("pnn", "Adam"), ("dcn", "SGD"), ("nfm", "Adagrad"), ("afm", "AdamW"),
+                                            ("ffm", "Adam"), ("ffm", "SGD")])
 def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tmp_path):
     """DistributedSparseTrainer (model forward under autograd, sharded lookups) against SparseTrainer on the union."""
     world = 2

@@ -229,6 +229,23 @@ def test_ffm(B, vocabs, d):
         # (rows spanning several chunks of the plan are summed chunk-wise: same terms, different association)
         close(dT2, dT, rtol=1e-5, atol=1e-6 * max(1.0, float(dT.abs().max())), msg="touched rows vs dense")
         close(parts.sum().cpu(), (dT2.double() ** 2).sum().float().cpu(), rtol=1e-5, atol=1e-12, msg="norm partials")
+        # the row-sharded path works on gathered rows: same term, and its row gradients add up to the same dT
+        flat = (idx + torch.tensor(layout.row_offsets, device=DEV).view(-1, 1)).t().contiguous()      # [B, F]
+        Gr = T[flat]                                                                                   # [B, F, F*d]
+        close(ops.ffm_rows_fwd(Gr, d), out, rtol=1e-6, atol=1e-7 * max(1.0, float(out.abs().max())), msg="rows fwd")
+        dG = ops.ffm_rows_bwd(Gr, gout.view(-1).to(DEV), d)
+        keep = (idx.t() > 0).reshape(-1)
+        dT3 = torch.zeros_like(T).index_add_(0, flat.reshape(-1)[keep], dG.view(B * Fn, Fn * d)[keep])
+        close(dT3, dT, rtol=1e-5, atol=1e-6 * max(1.0, float(dT.abs().max())), msg="rows bwd")
+        wp = ops.WidePlan(layout, cap=B, W=Fn * d)
+        wp.sort_columnar(idx)
+        wparts = torch.full((wp.n_partials_wide,), float("nan"), device=DEV)
+        wp.reduce_wide(wparts, dG.view(B * Fn, Fn * d))
+        dT4 = torch.zeros_like(T)
+        ops.call("rs_sparse_scatter_dense", ops.ptr(wp.plan), wp.F, wp.cap, wp.width, ops.ptr(wp.rowgrad_wide), None,
+                 ops.ptr(dT4), None, ops.stream())
+        close(dT4, dT, rtol=1e-5, atol=1e-6 * max(1.0, float(dT.abs().max())), msg="wide reduce")
+        close(wparts.sum().cpu(), (dT4.double() ** 2).sum().float().cpu(), rtol=1e-5, atol=1e-12, msg="wide norm partials")
         # SGD on the touched rows == dense SGD
         hyper = ops.make_hyper(DEV, 0.1)
         scal = torch.tensor([0.0, 0.5], device=DEV)
