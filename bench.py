@@ -225,8 +225,13 @@ def main():
         eng.use_graph = was_graph
     summ = timer.summary()
     final_loss = float(loss.item())
+    exchange_check = None
     if use_dist:
-        eng.check()          # bucket overflow / index range flags of the exchange (device sync, outside the timing)
+        try:
+            eng.check()      # bucket overflow / index range flags of the exchange (device sync, outside the timing)
+            exchange_check = "ok"
+        except Exception as e:       # reported with the result instead of losing the line
+            exchange_check = f"FAILED: {e}"
 
     if world > 1:
         import torch.distributed as dist
@@ -314,6 +319,8 @@ def main():
             "kernel_us_per_step": {k: round(v, 1) for k, v in per_step.items()},
             "kernels": kernels[:12], "final_loss": final_loss,
         }
+        if exchange_check is not None:
+            out["exchange_check"] = exchange_check
         print(json.dumps(out), flush=True)
     if use_dist:
         import gc
