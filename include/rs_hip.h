@@ -212,6 +212,14 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
                          const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                          float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
                          rs_stream_t stream);
+/* rs_sparse_bwd_reduce that also writes, from extra workgroups of its second launch, n_dense_partials
+ * sum-of-squares partials of a dense buffer (the flat gradient of the dense parameters): both are pieces of the one
+ * global norm of clip_grad_norm_ (BaseModel.py:148). */
+int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                               const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                               float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
+                               const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                               rs_stream_t stream);
 /* The same reduction for rows of W floats (W % 4 == 0, W <= 1024; field-aware FFM rows on the row-sharded path):
  * rowgrad[f, s, :] = sum of gout[sorted_src[q], :] over the entries of segment s, in ascending order; chunk_part
  * [F, cap, W] is scratch; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.  The plan's window L
@@ -223,6 +231,12 @@ int rs_sparse_bwd_reduce_wide(const int* plan, int F, int cap, int W, const floa
 int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                      float* table, float* m, float* v, float* table1, float* m1, float* v1, const float* hyper,
                      const float* scal, rs_stream_t stream);
+/* rs_sparse_update and rs_dense_update in one launch (optimizer.step() of BaseModel.py:149 over the touched table
+ * rows and the flat dense parameter buffer). */
+int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                           float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
+                           const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
+                           const float* scal, rs_stream_t stream);
 /* Expand row gradients into dense [R,d] / [R] gradients (pre-zeroed by the caller): what nn.Embedding's
  * autograd produces for torch's dense optimizers. */
 int rs_sparse_scatter_dense(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,

@@ -295,12 +295,10 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
-    __shared__ float red[4];
-    const int f = blockIdx.y;
+__device__ __forceinline__ void segment_finalize_body(const ReduceArgs& a, int f, int bx, int part_index, float* red) {
     const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
     const int gpb = 256 / a.C;
-    const int u = blockIdx.x * gpb + grp;
+    const int u = bx * gpb + grp;
     float nsq = 0.f;
     if (grp < gpb && u < a.counts[f * 4 + 2]) {
         const int* sf = a.seg_first_chunk + (long long)f * (a.cap + 1);
@@ -337,7 +335,34 @@ __global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
         if (cc == 0 && a.rowgrad1) { a.rowgrad1[(long long)f * a.cap + u] = acc1; nsq += acc1 * acc1; }
     }
     const float tot = rs_block_sum<256>(nsq, red);
-    if (threadIdx.x == 0) a.norm_partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.norm_partials[part_index] = tot;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_finalize_kernel(ReduceArgs a) {
+    __shared__ float red[4];
+    segment_finalize_body<VEC>(a, blockIdx.y, blockIdx.x, blockIdx.y * gridDim.x + blockIdx.x, red);
+}
+
+// segment_finalize for workgroups [0, F*gx) and, in the same launch, the sum-of-squares partials of a dense
+// buffer (the flat gradient of the dense parameters) for workgroups [F*gx, F*gx + n_dense_blocks): two
+// independent pieces of the global gradient norm in one launch.
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_finalize_sumsq_kernel(ReduceArgs a, int gx, const float* __restrict__ dense,
+                                                                     long long dense_n, float* __restrict__ dense_partials,
+                                                                     int n_dense_blocks) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, nsp = a.F * gx;
+    if (b < nsp) {
+        segment_finalize_body<VEC>(a, b / gx, b % gx, b, red);
+        return;
+    }
+    const int db = b - nsp;
+    float sq = 0.f;
+    const long long stride = (long long)n_dense_blocks * 256;
+    for (long long i = (long long)db * 256 + threadIdx.x; i < dense_n; i += stride) sq += dense[i] * dense[i];
+    const float tot = rs_block_sum<256>(sq, red);
+    if (threadIdx.x == 0) dense_partials[db] = tot;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -440,11 +465,10 @@ struct UpdateArgs {
 };
 
 template <int VEC>
-__global__ __launch_bounds__(256) void sparse_update_kernel(UpdateArgs a) {
-    const int f = blockIdx.y;
+__device__ __forceinline__ void sparse_update_body(const UpdateArgs& a, int f, int bx) {
     const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
     const int gpb = 256 / a.C;
-    const int u = blockIdx.x * gpb + grp;
+    const int u = bx * gpb + grp;
     if (grp >= gpb || u >= a.counts[f * 4 + 2]) return;
     const long long row = a.seg_row[(long long)f * a.cap + u];
     const float coef = a.scal ? a.scal[1] : 1.f;
@@ -467,6 +491,31 @@ __global__ __launch_bounds__(256) void sparse_update_kernel(UpdateArgs a) {
         opt_update(a.opt, a.hyper, a.rowgrad1[(long long)f * a.cap + u] * coef, w, a.m1 ? a.m1 + row : nullptr,
                    a.v1 ? a.v1 + row : nullptr);
         a.table1[row] = w;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sparse_update_kernel(UpdateArgs a) {
+    sparse_update_body<VEC>(a, blockIdx.y, blockIdx.x);
+}
+
+// The touched-rows step for workgroups [0, F*gx) and the flat dense step for the n_dense_blocks behind them: both
+// wait for the same clip coefficient and optimizer scalars, so they share one launch.
+template <int VEC>
+__global__ __launch_bounds__(256) void sparse_dense_update_kernel(UpdateArgs a, int gx, float* __restrict__ w,
+                                                                  const float* __restrict__ g, float* m, float* v,
+                                                                  long long n, int n_dense_blocks) {
+    const int b = blockIdx.x, nsp = a.F * gx;
+    if (b < nsp) {
+        sparse_update_body<VEC>(a, b / gx, b % gx);
+        return;
+    }
+    const float coef = a.scal ? a.scal[1] : 1.f;
+    const long long stride = (long long)n_dense_blocks * 256;
+    for (long long i = (long long)(b - nsp) * 256 + threadIdx.x; i < n; i += stride) {
+        float ww = w[i];
+        opt_update(a.opt, a.hyper, g[i] * coef, ww, m ? m + i : nullptr, v ? v + i : nullptr);
+        w[i] = ww;
     }
 }
 
@@ -696,6 +745,40 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
     return RS_OK;
 }
 
+// rs_sparse_bwd_reduce plus, in the launch of its second phase, the sum-of-squares partials of a dense buffer
+// (dense_partials[0 .. n_dense_partials), one per extra workgroup).
+int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                               const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                               float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
+                               const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                               hipStream_t stream) {
+    RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
+    RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce_sumsq: dfm needs S and emb");
+    RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce_sumsq: chunk_sum1/rowgrad1 mismatch");
+    RS_CHECK_ARG(Fdiv > 0, "rs_sparse_bwd_reduce_sumsq: Fdiv must be positive");
+    RS_CHECK_ARG(dense && dense_partials && dense_n >= 0 && n_dense_partials > 0, "rs_sparse_bwd_reduce_sumsq: bad dense arguments");
+    ReduceArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_reduce(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_bwd_reduce_sumsq: unsupported d=%d", d);
+    a.gout = gout; a.g1src = g1src; a.dfm = dfm; a.S = S; a.emb = emb; a.dlr = dlr; a.Fdiv = Fdiv;
+    a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
+    a.norm_partials = norm_partials;
+    a.L = window_for(d);
+    const int gx = rs_cdiv(cap, 256 / a.C);
+    dim3 block(256), wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F), fgrid(F * gx + n_dense_partials);
+    if (VEC == 4) {
+        hipLaunchKernelGGL(chunk_reduce_kernel<4>, wgrid, block, 0, stream, a);
+        hipLaunchKernelGGL(segment_finalize_sumsq_kernel<4>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
+                           n_dense_partials);
+    } else {
+        hipLaunchKernelGGL(chunk_reduce_kernel<1>, wgrid, block, 0, stream, a);
+        hipLaunchKernelGGL(segment_finalize_sumsq_kernel<1>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
+                           n_dense_partials);
+    }
+    RS_CHECK_LAUNCH("rs_sparse_bwd_reduce_sumsq");
+    return RS_OK;
+}
+
 static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, int* VEC) {
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     a.seg_row = pv.seg_row;
@@ -747,6 +830,36 @@ int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const floa
     if (VEC == 4) hipLaunchKernelGGL(sparse_update_kernel<4>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(sparse_update_kernel<1>, grid, block, 0, stream, a);
     RS_CHECK_LAUNCH("rs_sparse_update");
+    return RS_OK;
+}
+
+// rs_sparse_update and rs_dense_update (flat buffer dense_w / dense_g / dense_m / dense_v of dense_n floats) in one launch.
+int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                           float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
+                           const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
+                           const float* scal, hipStream_t stream) {
+    RS_CHECK_ARG(plan && hyper && dense_w && dense_g && dense_n >= 0, "rs_sparse_dense_update: null argument");
+    RS_CHECK_ARG(opt >= 0 && opt <= 3, "rs_sparse_dense_update: unknown optimizer %d", opt);
+    RS_CHECK_ARG(!table || rowgrad, "rs_sparse_dense_update: table without rowgrad");
+    RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_dense_update: table1 without rowgrad1");
+    if (opt == OPT_ADAM || opt == OPT_ADAMW)
+        RS_CHECK_ARG((!table || (m && v)) && (!table1 || (m1 && v1)) && dense_m && dense_v, "rs_sparse_dense_update: Adam needs m and v");
+    if (opt == OPT_ADAGRAD)
+        RS_CHECK_ARG((!table || m) && (!table1 || m1) && dense_m, "rs_sparse_dense_update: Adagrad needs the sum state in m");
+    UpdateArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_dense_update: unsupported d=%d", d);
+    a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.opt = opt; a.table = table; a.m = m; a.v = v;
+    a.table1 = table1; a.m1 = m1; a.v1 = v1; a.hyper = hyper; a.scal = scal;
+    const int gx = rs_cdiv(cap, 256 / a.C);
+    long long db = (dense_n + 255) / 256;
+    const int ndb = (int)(db > 2048 ? 2048 : (db < 1 ? 1 : db));
+    dim3 grid(F * gx + ndb), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(sparse_dense_update_kernel<4>, grid, block, 0, stream, a, gx, dense_w, dense_g, dense_m,
+                                     dense_v, dense_n, ndb);
+    else hipLaunchKernelGGL(sparse_dense_update_kernel<1>, grid, block, 0, stream, a, gx, dense_w, dense_g, dense_m, dense_v,
+                            dense_n, ndb);
+    RS_CHECK_LAUNCH("rs_sparse_dense_update");
     return RS_OK;
 }
 

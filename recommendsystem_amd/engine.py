@@ -133,6 +133,8 @@ class FusedTrainer:
         self._graphs = {}
         self._graph_pool = None
         self._capture_error_mode = "global"
+        # the base hooks run the whole step on this GPU; subclasses that put collectives between the pieces turn it off
+        self._fuse_small = type(self) is FusedTrainer
         self.last = {}
 
     # ------------------------------------------------------------------------------------------
@@ -268,24 +270,29 @@ class FusedTrainer:
     def _grad_scale(self) -> float:
         return 1.0
 
-    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already):
-        """Row gradients of the touched rows; fills plan.partials[:plan.n_partials] with ||g||^2 partials."""
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None):
+        """Row gradients of the touched rows; fills plan.partials[:plan.n_partials] with ||g||^2 partials.
+        dense_partials: also leave the ||g||^2 partials of the flat dense gradient there (same launch)."""
         B = idx.shape[1]
         if not sorted_already:
             plan.sort_columnar(idx)
         plan.reduce(plan.partials[:plan.n_partials], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
                     emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
-                    dlr=dz if self.has_lr else None, Fdiv=self.F)
+                    dlr=dz if self.has_lr else None, Fdiv=self.F,
+                    dense=self.flat_g if dense_partials is not None else None, dense_partials=dense_partials)
 
     def _reduce_dense_grads(self):
         """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
 
-    def _embed_update(self, plan):
+    def _embed_update(self, plan, with_dense=False):
         te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
-        plan.update(self.opt, self.hyper, self.scal,
-                    table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
-                    table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
-                    v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+        kw = dict(table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
+                  table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
+                  v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+        if with_dense:
+            plan.update_with_dense(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m, self.flat_v, **kw)
+        else:
+            plan.update(self.opt, self.hyper, self.scal, **kw)
 
     def _bump_bn_counters(self):
         for b in self.blocks:
@@ -405,7 +412,14 @@ class FusedTrainer:
         # ---- embedding backward: segment reduce of the sorted batch -----------------------------
         P = plan.partials
         n_sp = plan.n_partials
-        self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort)
+        dense_p = P[n_sp:n_sp + N_DENSE_PARTIALS]
+        # single GPU, no L2 term, everything on one stream: the dense gradient is final here, so its norm partials
+        # come out of the embedding reduction's second launch and the two optimizer steps share one launch
+        fuse = self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"
+        if fuse:
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort, dense_partials=dense_p)
+        else:
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort)
 
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
@@ -413,8 +427,8 @@ class FusedTrainer:
         self._reduce_dense_grads()
         if self.net_reg:
             ops.axpy(self.net_reg, self.flat_w, self.flat_g)
-        dense_p = P[n_sp:n_sp + N_DENSE_PARTIALS]
-        ops.sumsq_partials(self.flat_g, dense_p)
+        if not fuse:
+            ops.sumsq_partials(self.flat_g, dense_p)
         if self.mode == "sparse":
             norm_in = P[:n_sp + N_DENSE_PARTIALS]
         else:
@@ -434,8 +448,13 @@ class FusedTrainer:
             loss = self._add_reg_to_loss(loss)
 
         # ---- optimizer --------------------------------------------------------------------------
-        ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
-        if self.mode == "sparse":
+        if fuse:
+            self._embed_update(plan, with_dense=True)
+        else:
+            ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
+        if fuse:
+            pass
+        elif self.mode == "sparse":
             self._embed_update(plan)
         else:
             for t in self.tables:

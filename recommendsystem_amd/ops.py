@@ -452,15 +452,34 @@ class SparsePlan:
              stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
-               Fdiv=None):
-        """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats)."""
+               Fdiv=None, dense=None, dense_partials=None):
+        """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats).  dense / dense_partials: also
+        write the sum-of-squares partials of the flat buffer `dense` (one per element of dense_partials) from the
+        same launch."""
         if norm_partials.numel() < self.n_partials:
             raise RSError("sparse backward: norm_partials too small")
         for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
             _chk(t, torch.float32, n)
+        if dense is not None:
+            _chk(dense, torch.float32, "dense")
+            _chk(dense_partials, torch.float32, "dense_partials")
+            call("rs_sparse_bwd_reduce_sumsq", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm),
+                 ptr(S), ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1),
+                 ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense), dense.numel(),
+                 ptr(dense_partials), dense_partials.numel(), stream())
+            return
         call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(norm_partials), stream())
+
+    def update_with_dense(self, opt: str, hyper, scal, dense_w, dense_g, dense_m, dense_v, table=None, m=None, v=None,
+                          table1=None, m1=None, v1=None):
+        """Touched-rows step and the flat dense step in one launch."""
+        _chk(dense_w, torch.float32, "dense_w")
+        _chk(dense_g, torch.float32, "dense_g", dense_w.shape)
+        call("rs_sparse_dense_update", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
+             ptr(self.rowgrad1), ptr(table), ptr(m), ptr(v), ptr(table1), ptr(m1), ptr(v1), ptr(dense_w), ptr(dense_g),
+             ptr(dense_m), ptr(dense_v), dense_w.numel(), ptr(hyper), ptr(scal), stream())
 
     def update(self, opt: str, hyper, scal, table=None, m=None, v=None, table1=None, m1=None, v1=None):
         call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
