@@ -204,6 +204,13 @@ int rs_sparse_window(int d);
 int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base, int pay_stride,
                        int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
                        const int64_t* row_offset, int* plan, rs_stream_t stream);
+/* rs_sparse_bwd_sort of a columnar batch idx [F, B] (sub_off[f] = f*B, sub_cnt[f] = B, pay_base[f] = f, stride F)
+ * and rs_gather_lr_fm_fwd of the same batch in ONE launch: both need only the batch, and the sort occupies just F
+ * workgroups, so the gather runs beside it (Layers.py:137-160 forward + the index bookkeeping of its backward). */
+int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
+                   const int64_t* vocab, const int64_t* row_offset, int* plan, const float* table, const float* table1,
+                   const float* bias, float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B,
+                   int F, int d, int* err_flag, rs_stream_t stream);
 /* Row gradient of every touched row = sum over its entries r (sample b = r / Fdiv) of
  *   gout[r,:] + dfm[b]*(S[b,:] - emb[r,:])      and, for the 1-dim tables, g1src[r] + dlr[b]
  * (each term optional).  Also writes rs_sparse_bwd_num_partials(F,cap,d) partial sums of ||g||^2. */

@@ -35,6 +35,8 @@ _SIGS = {
     "rs_colsum_finish_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     # sparse.hip
     "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
+    "rs_sort_gather": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                       c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
                              c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_sparse_bwd_reduce_sumsq": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,

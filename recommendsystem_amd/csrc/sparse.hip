@@ -18,6 +18,7 @@
 //      scatter_rowgrad      alternative consumer: expand into a dense (R, d) gradient for callers
 //                           that keep the reference's dense torch optimizers.
 #include "common.h"
+#include "gather_body.h"
 #include "plan.h"
 
 namespace {
@@ -66,10 +67,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int
 }
 
 template <int ITEMS>
-__global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
+__device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*ITEMS]
     int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32]
-    const int f = blockIdx.x;
     const int t = threadIdx.x;
     constexpr int CAPB = SORT_THREADS * ITEMS;
 
@@ -197,6 +197,23 @@ __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
         int* c = a.counts + f * 4;
         c[0] = n; c[1] = n_chunk; c[2] = n_seg; c[3] = totpad;
     }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
+    field_sort_body<ITEMS>(a, blockIdx.x);
+}
+
+// The index sort of a batch and its fused gather (K1) need nothing but the batch, and the sort keeps only F
+// workgroups busy: one launch runs the F sort workgroups first and the gather on the workgroups behind them, so the
+// gather costs no time of its own.
+template <int ITEMS, int VEC>
+__global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(SortArgs a, GatherArgs ga) {
+    if ((int)blockIdx.x < a.F) {
+        field_sort_body<ITEMS>(a, blockIdx.x);
+        return;
+    }
+    gather_fused_body<VEC>(ga, ((int)blockIdx.x - a.F) * (SORT_THREADS / 64) + (threadIdx.x >> 6));
 }
 
 // -------------------------------------------------------------------------------------------
@@ -694,6 +711,59 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     else RS_SORT_LAUNCH(16);
 #undef RS_SORT_LAUNCH
     RS_CHECK_LAUNCH("rs_sparse_bwd_sort");
+    return RS_OK;
+}
+
+// rs_sparse_bwd_sort of a columnar batch idx [F, B] (entry (f, b) names gradient row b*F + f) and
+// rs_gather_lr_fm_fwd of the same batch in one launch.
+int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
+                   const int64_t* vocab, const int64_t* row_offset, int* plan, const float* table, const float* table1,
+                   const float* bias, float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B,
+                   int F, int d, int* err_flag, hipStream_t stream) {
+    RS_CHECK_ARG(idx && sub_off && sub_cnt && pay_base && vocab && row_offset && plan, "rs_sort_gather: null argument");
+    RS_CHECK_ARG(B > 0 && F > 0 && d > 0 && L > 0 && cap >= B, "rs_sort_gather: bad sizes");
+    RS_CHECK_ARG(B <= SORT_THREADS * 16, "rs_sort_gather: %d entries per field exceed the in-LDS sort limit %d", B,
+                 SORT_THREADS * 16);
+    RS_CHECK_ARG(table || table1, "rs_sort_gather: both tables are null");
+    RS_CHECK_ARG(table || !(emb_out || sum_out || bi_out || fm_out), "rs_sort_gather: embedding outputs requested without a table");
+    RS_CHECK_ARG(table1 || !lr_out, "rs_sort_gather: lr_out requested without table1");
+    SortArgs a;
+    a.keys = idx; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = F;
+    a.nsrc = 1; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
+    const PlanView pv = carve_plan(plan, F, cap);
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.entry_seg = pv.entry_seg;
+    a.chunk_start = pv.chunk_start; a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk;
+    a.counts = pv.counts;
+    GatherArgs ga{idx, row_offset, vocab, table, table1, bias, emb_out, sum_out, bi_out, lr_out, fm_out, err_flag, B, F, d, 1, 1};
+    int VEC = 1;
+    if (!table) { VEC = 1; ga.C = 1; ga.G = 8; ga.d = 1; }
+    else RS_CHECK_ARG(pick_layout(d, &VEC, &ga.G, &ga.C) == 0, "rs_sort_gather: unsupported embedding_dim %d", d);
+    const int spw = 64 / (ga.G * ga.C);
+    const int gblocks = rs_cdiv(rs_cdiv(B, spw), SORT_THREADS / 64);
+    int items = 1;
+    while (items * SORT_THREADS < B) items <<= 1;
+    if (items < 4) items = 4;
+    const size_t smem = (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int);
+#define RS_SG_LAUNCH(IT, V)                                                                         \
+    do {                                                                                            \
+        static bool attr = false;                                                                   \
+        if (!attr) {                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_gather_kernel<IT, V>),       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
+                rs_set_error("rs_sort_gather: cannot reserve %zu bytes of LDS", smem);              \
+                return RS_ERR_LAUNCH;                                                               \
+            }                                                                                       \
+            attr = true;                                                                            \
+        }                                                                                           \
+        hipLaunchKernelGGL((sort_gather_kernel<IT, V>), dim3(F + gblocks), dim3(SORT_THREADS), smem, stream, a, ga); \
+    } while (0)
+    if (VEC == 4) {
+        if (items == 4) RS_SG_LAUNCH(4, 4); else if (items == 8) RS_SG_LAUNCH(8, 4); else RS_SG_LAUNCH(16, 4);
+    } else {
+        if (items == 4) RS_SG_LAUNCH(4, 1); else if (items == 8) RS_SG_LAUNCH(8, 1); else RS_SG_LAUNCH(16, 1);
+    }
+#undef RS_SG_LAUNCH
+    RS_CHECK_LAUNCH("rs_sort_gather");
     return RS_OK;
 }
 

@@ -214,13 +214,14 @@ class FusedTrainer:
         return self._plans[B]
 
     # ------------------------------------------------------------------------------------------
-    def forward_parts(self, idx: torch.Tensor, defer_head: bool = False):
+    def forward_parts(self, idx: torch.Tensor, defer_head: bool = False, sort_plan=None):
         """Forward pass; returns (logit parts, saved context).  defer_head: leave a 1-wide last block to the
-        caller (the training step fuses it with the loss head); then ctx["head_in"] is its input."""
+        caller (the training step fuses it with the loss head); then ctx["head_in"] is its input.  sort_plan: also
+        sort the batch into this plan, in the gather's launch."""
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
-        r = self._embed_forward(idx)
+        r = self._embed_forward(idx) if sort_plan is None else self._embed_forward_sorting(idx, sort_plan)
         ctx["emb"] = r.get("emb")
         ctx["S"] = r.get("sum")
         if self.has_lr:
@@ -266,6 +267,14 @@ class FusedTrainer:
         bias = self.lrm.bias.data if self.has_lr else None
         return ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
                                     want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
+
+    def _embed_forward_sorting(self, idx, plan):
+        """_embed_forward plus the index sort of the sparse backward in the same launch."""
+        table = self.tab.stacked if self.has_emb else None
+        table1 = self.tab1.stacked if self.has_lr else None
+        bias = self.lrm.bias.data if self.has_lr else None
+        return plan.sort_and_gather(idx, table, table1, bias, want_emb=self.has_emb, want_sum=self.has_fm,
+                                    want_lr=self.has_lr, want_fm=self.has_fm)
 
     def _grad_scale(self) -> float:
         return 1.0
@@ -326,7 +335,9 @@ class FusedTrainer:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
         head_fast = bool(self.blocks) and self._head_fast
-        parts, ctx = self.forward_parts(idx, defer_head=head_fast)
+        # single GPU, one stream: the sort shares the gather's launch (it keeps only F workgroups busy)
+        sort_early = self._fuse_small and not fork_sort
+        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
         lastb = self.blocks[-1] if self.blocks else None
         if head_fast:
             # the 1-wide last block, the loss and dL/dlogit in one launch
@@ -417,9 +428,9 @@ class FusedTrainer:
         # come out of the embedding reduction's second launch and the two optimizer steps share one launch
         fuse = self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"
         if fuse:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort, dense_partials=dense_p)
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p)
         else:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort)
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early)
 
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on

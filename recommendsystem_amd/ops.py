@@ -442,6 +442,40 @@ class SparsePlan:
         call("rs_sparse_bwd_sort", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.F, 1, self.F, self.cap, B,
              self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan), stream())
 
+    def sort_and_gather(self, idx: torch.Tensor, table, table1, bias, want_emb=True, want_sum=False, want_lr=False,
+                        want_fm=False):
+        """sort_columnar(idx) and gather_lr_fm_fwd(idx, ...) in one launch; returns the gather's dict."""
+        Fn, B = idx.shape
+        _chk(idx, torch.int64, "idx", (self.F, B))
+        if B > self.cap:
+            raise RSError(f"sparse backward: batch {B} exceeds plan capacity {self.cap}")
+        layout = self.layout
+        d = 1
+        if table is not None:
+            d = table.shape[1]
+            _chk(table, torch.float32, "table", (layout.total_rows, d))
+        if table1 is not None:
+            if table1.dim() == 2 and table1.shape[1] == 1:
+                table1 = table1.view(-1)
+            _chk(table1, torch.float32, "table1", (layout.total_rows,))
+        _chk(bias, torch.float32, "bias", (1,))
+        dev = idx.device
+        out = {}
+        if want_emb:
+            out["emb"] = torch.empty((B, Fn, d), dtype=torch.float32, device=dev)
+        if want_sum:
+            out["sum"] = torch.empty((B, d), dtype=torch.float32, device=dev)
+        if want_lr:
+            out["lr"] = torch.empty((B,), dtype=torch.float32, device=dev)
+        if want_fm:
+            out["fm"] = torch.empty((B,), dtype=torch.float32, device=dev)
+        off, cnt, base = self.columnar_lists(B)
+        call("rs_sort_gather", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK, ptr(layout.vocab_t),
+             ptr(layout.row_offset_t), ptr(self.plan), ptr(table), ptr(table1), ptr(bias), ptr(out.get("emb")),
+             ptr(out.get("sum")), ptr(None), ptr(out.get("lr")), ptr(out.get("fm")), B, Fn, d, ptr(layout.err_flag),
+             stream())
+        return out
+
     def sort_lists(self, keys, sub_off, sub_cnt, pay_base, nsrc: int, max_entries: int):
         """General form: per field, `nsrc` packed sub-lists of keys; gradient rows are packed likewise."""
         _chk(keys, torch.int64, "keys")
