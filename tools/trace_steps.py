@@ -1,5 +1,5 @@
 """Per-step kernel breakdown from a rocprofv3 kernel trace of bench.py: steps are delimited by the fused gather
-launch; the fastest `--keep` steps (the graph replays of the timed region) are averaged."""
+launch (alone or sharing its launch with the index sort); the fastest `--keep` steps (the graph replays of the timed region) are averaged."""
 import csv
 import sys
 from collections import defaultdict
@@ -11,7 +11,7 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "gather_fused_kernel" in r[2]]
+starts = [i for i, r in enumerate(rows) if "gather_fused_kernel" in r[2] or "sort_gather_kernel" in r[2]]
 steps = []
 for a, b in zip(starts, starts[1:]):
     steps.append((rows[b][0] - rows[a][0], a, b))
