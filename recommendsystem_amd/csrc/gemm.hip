@@ -22,6 +22,7 @@
 // k); the next tile's global loads are issued before the MFMAs of the current tile and written to
 // the other LDS buffer after them (one barrier per k-tile).
 #include "common.h"
+#include "colsum_finish.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -824,39 +825,9 @@ __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restr
     if (r == 0 && n < N) out[n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// Several column-sum reductions in one launch: problem p adds the `rows[p]` partial rows part[p][r*ld[p] + n]
-// (n < n[p]) in row order into out[p][n].  16 columns per workgroup: thread (c = tid % 16, r = tid / 16) adds
-// rows r, r+16, ..., then the 16 row groups of a column meet in LDS.
-constexpr int CF_MAX = 8;
-struct ColsumFinishArgs {
-    const float* part[CF_MAX]; float* out[CF_MAX];
-    int rows[CF_MAX], n[CF_MAX], ld[CF_MAX], first_block[CF_MAX + 1];
-    int count;
-};
 __global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumFinishArgs a) {
     __shared__ float red[16][17];
-    int p = 0;
-    while (p + 1 < a.count && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
-    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int n = ((int)blockIdx.x - a.first_block[p]) * 16 + c;
-    const float* part = a.part[p];
-    const int rows = a.rows[p], ld = a.ld[p];
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < a.n[p]) {
-        for (int g = r; g < rows; g += 64) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (g + 16 * u < rows) s[u] += part[(long long)(g + 16 * u) * ld + n];
-        }
-    }
-    red[r][c] = (s[0] + s[1]) + (s[2] + s[3]);
-    __syncthreads();
-    if (r == 0 && n < a.n[p]) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][c];
-        a.out[p][n] = t;
-    }
+    colsum_finish_body(a, blockIdx.x, red);
 }
 
 }  // namespace
@@ -948,15 +919,8 @@ int rs_colsum_finish_multi(const float* const* part, const int* rows, const int*
     if (count == 0) return RS_OK;
     RS_CHECK_ARG(part && rows && n && ld && out, "rs_colsum_finish_multi: null argument");
     ColsumFinishArgs a;
-    int blocks = 0;
-    for (int p = 0; p < count; ++p) {
-        RS_CHECK_ARG(part[p] && out[p] && rows[p] >= 0 && n[p] > 0 && ld[p] >= n[p], "rs_colsum_finish_multi: bad problem %d", p);
-        a.part[p] = part[p]; a.out[p] = out[p]; a.rows[p] = rows[p]; a.n[p] = n[p]; a.ld[p] = ld[p];
-        a.first_block[p] = blocks;
-        blocks += rs_cdiv(n[p], 16);
-    }
-    a.first_block[count] = blocks;
-    a.count = count;
+    const int blocks = colsum_finish_fill(a, part, rows, n, ld, out, count);
+    RS_CHECK_ARG(blocks >= 0, "rs_colsum_finish_multi: bad problem (null pointer, negative rows or ld < n)");
     hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
     RS_CHECK_LAUNCH("rs_colsum_finish_multi");
     return RS_OK;

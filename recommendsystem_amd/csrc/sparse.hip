@@ -18,6 +18,7 @@
 //      scatter_rowgrad      alternative consumer: expand into a dense (R, d) gradient for callers
 //                           that keep the reference's dense torch optimizers.
 #include "common.h"
+#include "colsum_finish.h"
 #include "gather_body.h"
 #include "plan.h"
 
@@ -258,10 +259,9 @@ constexpr int RU = 8;   // chunk sums in flight per lane group (segment_finalize
 // shuffle tree keyed by the chunk id -- leaves each chunk's sum in its last entry.  Chunks never
 // cross a window (chunk heads fall on every multiple of L), so no carries leave the wave.
 template <int VEC>
-__global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
-    const int f = blockIdx.y;
+__device__ __forceinline__ void chunk_reduce_body(const ReduceArgs& a, int f, int bx) {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = bx * 4 + (threadIdx.x >> 6);
     const int n = a.counts[f * 4 + 0];
     if (w * a.L >= n) return;                              // wave-uniform
     const int e = lane / a.C, cc = lane - e * a.C;
@@ -309,6 +309,21 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
         stv<VEC>(a.chunk_sum + ((long long)f * a.cap + cid) * d + co, g);
         if (cc == 0 && a.chunk_sum1) a.chunk_sum1[(long long)f * a.cap + cid] = g1;
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
+    chunk_reduce_body<VEC>(a, blockIdx.y, blockIdx.x);
+}
+
+// chunk_reduce for workgroups [0, F*wx) and, behind them, the finishing additions of the partial column sums the
+// dense backward left (bias gradients): independent work that waits for the same predecessors.
+template <int VEC>
+__global__ __launch_bounds__(256) void chunk_reduce_colsum_kernel(ReduceArgs a, int wx, ColsumFinishArgs cf) {
+    __shared__ float red[16][17];
+    const int b = blockIdx.x, nsp = a.F * wx;
+    if (b < nsp) chunk_reduce_body<VEC>(a, b / wx, b % wx);
+    else colsum_finish_body(cf, b - nsp, red);
 }
 
 template <int VEC>
@@ -816,13 +831,24 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
 }
 
 // rs_sparse_bwd_reduce plus, in the launch of its second phase, the sum-of-squares partials of a dense buffer
-// (dense_partials[0 .. n_dense_partials), one per extra workgroup).
+// (dense_partials[0 .. n_dense_partials), one per extra workgroup) and, in the launch of its first phase, the
+// cs_count column-sum finishes of rs_colsum_finish_multi (cs_* as that entry point's arguments; cs_count may be 0).
+// The finished column sums may be part of `dense`: the second launch starts after the first has ended.
 int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                                float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
-                               hipStream_t stream) {
+                               const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
+                               float* const* cs_out, int cs_count, hipStream_t stream) {
     RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
+    RS_CHECK_ARG(cs_count >= 0 && cs_count <= CF_MAX, "rs_sparse_bwd_reduce_sumsq: at most %d column-sum problems", CF_MAX);
+    ColsumFinishArgs cf{};
+    int cs_blocks = 0;
+    if (cs_count > 0) {
+        RS_CHECK_ARG(cs_part && cs_rows && cs_n && cs_ld && cs_out, "rs_sparse_bwd_reduce_sumsq: null column-sum arrays");
+        cs_blocks = colsum_finish_fill(cf, cs_part, cs_rows, cs_n, cs_ld, cs_out, cs_count);
+        RS_CHECK_ARG(cs_blocks >= 0, "rs_sparse_bwd_reduce_sumsq: bad column-sum problem");
+    }
     RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce_sumsq: dfm needs S and emb");
     RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce_sumsq: chunk_sum1/rowgrad1 mismatch");
     RS_CHECK_ARG(Fdiv > 0, "rs_sparse_bwd_reduce_sumsq: Fdiv must be positive");
@@ -836,12 +862,16 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     a.L = window_for(d);
     const int gx = rs_cdiv(cap, 256 / a.C);
     dim3 block(256), wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F), fgrid(F * gx + n_dense_partials);
+    const int wx = (int)wgrid.x;
+    dim3 cgrid(F * wx + cs_blocks);
     if (VEC == 4) {
-        hipLaunchKernelGGL(chunk_reduce_kernel<4>, wgrid, block, 0, stream, a);
+        if (cs_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<4>, cgrid, block, 0, stream, a, wx, cf);
+        else hipLaunchKernelGGL(chunk_reduce_kernel<4>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_sumsq_kernel<4>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
                            n_dense_partials);
     } else {
-        hipLaunchKernelGGL(chunk_reduce_kernel<1>, wgrid, block, 0, stream, a);
+        if (cs_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<1>, cgrid, block, 0, stream, a, wx, cf);
+        else hipLaunchKernelGGL(chunk_reduce_kernel<1>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_sumsq_kernel<1>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
                            n_dense_partials);
     }

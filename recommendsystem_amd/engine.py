@@ -279,7 +279,7 @@ class FusedTrainer:
     def _grad_scale(self) -> float:
         return 1.0
 
-    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None):
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None):
         """Row gradients of the touched rows; fills plan.partials[:plan.n_partials] with ||g||^2 partials.
         dense_partials: also leave the ||g||^2 partials of the flat dense gradient there (same launch)."""
         B = idx.shape[1]
@@ -288,7 +288,8 @@ class FusedTrainer:
         plan.reduce(plan.partials[:plan.n_partials], gout=gout, dfm=dz if self.has_fm else None, S=ctx["S"],
                     emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
                     dlr=dz if self.has_lr else None, Fdiv=self.F,
-                    dense=self.flat_g if dense_partials is not None else None, dense_partials=dense_partials)
+                    dense=self.flat_g if dense_partials is not None else None, dense_partials=dense_partials,
+                    colsum=colsum)
 
     def _reduce_dense_grads(self):
         """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
@@ -356,6 +357,7 @@ class FusedTrainer:
         # Critical chain on the main stream: dZ_l -> dX -> dZ_(l-1) ...; the weight/bias gradients of
         # a layer depend only on its dZ and run beside the chain on the side stream.
         gout = None
+        pending_colsum = None
         if self.blocks:
             cs = ctx["mlp"]
             dh = dz.view(B, 1)
@@ -415,7 +417,11 @@ class FusedTrainer:
                     db_done = False
                 dz_ready = fuse_prev
                 keep.append(dh)
-            csp.finish()
+            # the bias-gradient finishes: beside the first launch of the embedding reduction when that is fused
+            if self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse":
+                pending_colsum = csp.hand_over()
+            else:
+                csp.finish()
             gout = dh.view(B * self.F, self.d)
 
         if fork_sort:
@@ -428,7 +434,8 @@ class FusedTrainer:
         # come out of the embedding reduction's second launch and the two optimizer steps share one launch
         fuse = self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"
         if fuse:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p)
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p,
+                                 colsum=pending_colsum)
         else:
             self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early)
 

@@ -238,18 +238,29 @@ class ColsumParts:
         _chk(dest, torch.float32, "colsum destination", (n,))
         self._items.append((part, int(rows), int(n), int(ld), dest, int(offset)))
 
-    def finish(self):
+    @staticmethod
+    def _arrays(grp):
         import ctypes as C
+        k = len(grp)
+        P = (C.c_void_p * k)(*[g[0].data_ptr() + 4 * g[5] for g in grp])
+        O = (C.c_void_p * k)(*[g[4].data_ptr() for g in grp])
+        R = (C.c_int * k)(*[g[1] for g in grp])
+        Nn = (C.c_int * k)(*[g[2] for g in grp])
+        L = (C.c_int * k)(*[g[3] for g in grp])
+        return P, R, Nn, L, O, k
+
+    def finish(self):
         items, self._items, self._k = self._items, [], 0
         for i in range(0, len(items), 8):
-            grp = items[i:i + 8]
-            k = len(grp)
-            P = (C.c_void_p * k)(*[g[0].data_ptr() + 4 * g[5] for g in grp])
-            O = (C.c_void_p * k)(*[g[4].data_ptr() for g in grp])
-            R = (C.c_int * k)(*[g[1] for g in grp])
-            Nn = (C.c_int * k)(*[g[2] for g in grp])
-            L = (C.c_int * k)(*[g[3] for g in grp])
-            call("rs_colsum_finish_multi", P, R, Nn, L, O, k, stream())
+            call("rs_colsum_finish_multi", *self._arrays(items[i:i + 8]), stream())
+
+    def hand_over(self):
+        """The pending problems as the (part, rows, n, ld, out, count) argument arrays of one finishing launch, for a
+        consumer that runs them inside a launch of its own; anything beyond eight problems is finished here."""
+        items, self._items, self._k = self._items, [], 0
+        for i in range(8, len(items), 8):
+            call("rs_colsum_finish_multi", *self._arrays(items[i:i + 8]), stream())
+        return self._arrays(items[:8]) if items else None
 
 
 def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None, scale=None) -> torch.Tensor:
@@ -486,10 +497,10 @@ class SparsePlan:
              stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
-               Fdiv=None, dense=None, dense_partials=None):
+               Fdiv=None, dense=None, dense_partials=None, colsum=None):
         """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats).  dense / dense_partials: also
         write the sum-of-squares partials of the flat buffer `dense` (one per element of dense_partials) from the
-        same launch."""
+        same launch.  colsum: ColsumParts.hand_over() -- those finishes run beside the first launch."""
         if norm_partials.numel() < self.n_partials:
             raise RSError("sparse backward: norm_partials too small")
         for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
@@ -500,8 +511,10 @@ class SparsePlan:
             call("rs_sparse_bwd_reduce_sumsq", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm),
                  ptr(S), ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1),
                  ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense), dense.numel(),
-                 ptr(dense_partials), dense_partials.numel(), stream())
+                 ptr(dense_partials), dense_partials.numel(), *(colsum or (None, None, None, None, None, 0)), stream())
             return
+        if colsum is not None:
+            raise RSError("sparse backward: column-sum finishes ride only with the dense-norm form of the reduction")
         call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(norm_partials), stream())
