@@ -73,6 +73,14 @@ int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out /* host pointer *
 int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
                 float* workspace, size_t workspace_bytes, float* colsum_part, rs_stream_t stream);
+/* A split product without its reducing launch: the splitk slabs [splitk, M, N] stay in `workspace` until
+ * rs_splitk_reduce_multi adds them, in slab order, into contiguous [M, N] outputs for up to 8 such products in one
+ * launch (host arrays of device pointers / element counts / split counts).  Used for the weight gradients of a
+ * backward pass (Layers.py:42 nn.Linear under autograd), which nothing reads before the gradient norm. */
+int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int tile,
+                      int splitk, float* workspace, size_t workspace_bytes, rs_stream_t stream);
+int rs_splitk_reduce_multi(const float* const* ws, float* const* C, const long long* total, const int* splitk, int count,
+                           rs_stream_t stream);
 /* out[p][n] = sum_{r < rows[p]} part[p][r*ld[p] + n] for n < n[p], p < count <= 8, in one launch.  The five arrays
  * are HOST arrays (of device pointers / sizes). */
 int rs_colsum_finish_multi(const float* const* part, const int* rows, const int* n, const int* ld, float* const* out,

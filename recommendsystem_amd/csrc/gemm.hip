@@ -47,6 +47,7 @@ struct GemmArgs {
     int dbg;                // ablation experiments (builds with -DRS_GEMM_EXPERIMENT read RS_GEMM_DBG):
                             // 1 = no DMA in the k loop, 2 = no stores, 4 = no MFMA, 8 = no barrier in the k loop,
                             // 16 = no LDS fragment reads after the first k-tile
+    int defer;              // splitk > 1: leave the slabs in ws, the caller reduces them later (rs_splitk_reduce_multi)
 };
 #ifdef RS_GEMM_EXPERIMENT
 #define RS_DBG(g) ((g).dbg)
@@ -682,6 +683,42 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     }
 }
 
+// The same for several deferred products in one launch (no epilogue): product p owns workgroups
+// [first_block[p], first_block[p+1]); float4 where the buffers allow it.
+constexpr int SK_MAX = 8;
+struct SplitKMultiArgs {
+    const float* ws[SK_MAX]; float* C[SK_MAX];
+    long long total[SK_MAX];
+    int splitk[SK_MAX], vec[SK_MAX], first_block[SK_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(SplitKMultiArgs a) {
+    int p = 0;
+    while (p + 1 < a.count && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
+    const int nb = a.first_block[p + 1] - a.first_block[p], b = (int)blockIdx.x - a.first_block[p];
+    const long long total = a.total[p], stride = (long long)nb * 256;
+    const float* ws = a.ws[p];
+    float* C = a.C[p];
+    const int sk = a.splitk[p];
+    if (a.vec[p]) {
+        const long long t4 = total / 4;
+        for (long long e = (long long)b * 256 + threadIdx.x; e < t4; e += stride) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < sk; ++z) {
+                const float4 t = reinterpret_cast<const float4*>(ws + z * total)[e];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            reinterpret_cast<float4*>(C)[e] = v;
+        }
+    } else {
+        for (long long e = (long long)b * 256 + threadIdx.x; e < total; e += stride) {
+            float v = 0.f;
+            for (int z = 0; z < sk; ++z) v += ws[z * total + e];
+            C[e] = v;
+        }
+    }
+}
+
 template <int BM, int BN, bool A_MC, bool B_NC, bool VA, bool VB>
 int launch(const GemmArgs& g, hipStream_t stream) {
     using SA = Stage<BM, A_MC, VA>;
@@ -700,7 +737,7 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     dim3 grid(rs_cdiv(g.N, BN), rs_cdiv(g.M, BM), g.splitk), block(256);
     hipLaunchKernelGGL(kern, grid, block, smem, stream, g);
     RS_CHECK_LAUNCH("rs_gemm_f32");
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.defer) {
         const long long total = (long long)g.M * g.N;
         int blocks = (int)min((long long)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
@@ -725,7 +762,7 @@ int launch_dma(const GemmArgs& g, hipStream_t stream) {
     dim3 grid(rs_cdiv(g.N, BN), rs_cdiv(g.M, BM), g.splitk), block(256);
     hipLaunchKernelGGL(kern, grid, block, smem, stream, g);
     RS_CHECK_LAUNCH("rs_gemm_f32");
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.defer) {
         const long long total = (long long)g.M * g.N;
         int blocks = (int)min((long long)2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
@@ -866,10 +903,10 @@ int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile 
 // colsum_part (optional, [rs_gemm_colsum_rows(M, tile), N], needs an explicit tile and a resolved splitk of 1):
 // receives per-wave-row column sums of the finished C; their sum over rows (rs_colsum_finish_multi) is
 // sum_m C[m, n] -- the bias gradient when C is a dZ.
-int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
-                int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part,
-                hipStream_t stream) {
+static int gemm_impl(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
+                     int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part, int defer,
+                     hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "rs_gemm_f32: negative size");
     if (M == 0 || N == 0) return RS_OK;
     RS_CHECK_ARG(A && B && C, "rs_gemm_f32: null operand");
@@ -899,7 +936,8 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
     const bool vec_epi = allow_vec && N % 4 == 0 && aligned16(C) && ldc % 4 == 0 && (!bias || aligned16(bias)) &&
                          (!mulsrc || (aligned16(mulsrc) && ldm % 4 == 0)) && (splitk == 1 || aligned16(workspace));
     GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part,
-               vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg};
+               vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg, defer};
+    RS_CHECK_ARG(!defer || splitk > 1, "rs_gemm_f32_slabs: the reduction did not split (splitk resolved to %d)", splitk);
     g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
     const bool va = aligned16(A) && lda % 4 == 0 && (a_mc ? M % 4 == 0 : K % 4 == 0);
@@ -909,6 +947,50 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
     if (!a_mc && !b_nc) return dispatch<false, false>(g, va, vb, tile, stream);
     if (!a_mc && b_nc) return dispatch<false, true>(g, va, vb, tile, stream);
     return dispatch<true, true>(g, va, vb, tile, stream);
+}
+
+int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
+                int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part,
+                hipStream_t stream) {
+    return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mulsrc, ldm, mul_act, tile, splitk, workspace,
+                     workspace_bytes, colsum_part, 0, stream);
+}
+
+// The split-K product without its reducing launch: the splitk slabs [splitk, M, N] stay in `workspace` (which must
+// stay untouched until they are reduced) and C is written by a later rs_splitk_reduce_multi, which serves several
+// such products in one launch.  tile >= 0 and splitk > 1 are required; no epilogue.
+int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int tile,
+                      int splitk, float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    RS_CHECK_ARG(tile >= 0 && splitk > 1 && workspace, "rs_gemm_f32_slabs: needs an explicit tile, splitk > 1 and a workspace");
+    RS_CHECK_ARG(splitk <= rs_cdiv(K, BK), "rs_gemm_f32_slabs: splitk %d exceeds the k-tiles of K=%d", splitk, K);
+    return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, workspace, N, nullptr, RS_ACT_NONE, nullptr, 0, 0, tile, splitk,
+                     workspace, workspace_bytes, nullptr, 1, stream);
+}
+
+// C[p][e] = sum_z ws[p][z * total[p] + e], z < splitk[p] in slab order, e < total[p], for p < count (<= 8) products in
+// one launch.  All four arrays are HOST arrays of length count (the pointers in them are device pointers).
+int rs_splitk_reduce_multi(const float* const* ws, float* const* C, const long long* total, const int* splitk, int count,
+                           hipStream_t stream) {
+    RS_CHECK_ARG(count >= 0 && count <= SK_MAX, "rs_splitk_reduce_multi: at most %d products", SK_MAX);
+    if (count == 0) return RS_OK;
+    RS_CHECK_ARG(ws && C && total && splitk, "rs_splitk_reduce_multi: null argument");
+    SplitKMultiArgs a;
+    int blocks = 0;
+    for (int p = 0; p < count; ++p) {
+        RS_CHECK_ARG(ws[p] && C[p] && total[p] > 0 && splitk[p] > 0, "rs_splitk_reduce_multi: bad product %d", p);
+        a.ws[p] = ws[p]; a.C[p] = C[p]; a.total[p] = total[p]; a.splitk[p] = splitk[p];
+        a.vec[p] = (aligned16(ws[p]) && aligned16(C[p]) && total[p] % 4 == 0) ? 1 : 0;
+        a.first_block[p] = blocks;
+        const long long units = a.vec[p] ? total[p] / 4 : total[p];
+        long long b = (units + 255) / 256;
+        blocks += (int)(b > 1024 ? 1024 : b);
+    }
+    a.first_block[count] = blocks;
+    a.count = count;
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    RS_CHECK_LAUNCH("rs_splitk_reduce_multi");
+    return RS_OK;
 }
 
 // out[p][n] = sum_r part[p][r*ld[p] + n], r < rows[p], n < n[p], for p < count (<= 8) problems in one launch.

@@ -371,6 +371,8 @@ class FusedTrainer:
                 else:
                     fn()
 
+            # weight gradients are read by nobody before the gradient norm: their split-K slabs are reduced together
+            skp = ops.SplitKParts(ops.default_workspace(self.device)) if not overlap else None
             db_done = False              # the bias gradient of the block about to be visited is already on its way
             csp = ops.ColsumParts(ops.default_workspace(self.device))    # partial column sums -> one finishing launch
             if head_fast:
@@ -392,9 +394,10 @@ class FusedTrainer:
                     keep.append(dzl)
                     gW, gb = self.gviews[id(b.fc.weight)], self.gviews[id(b.fc.bias)]
                     if db_done:
-                        wgrad(lambda dzl=dzl, c=c, gW=gW: ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW))
+                        wgrad(lambda dzl=dzl, c=c, gW=gW: ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW, defer_reduce=skp))
                     else:
-                        wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW),
+                        wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW,
+                                                                           defer_reduce=skp),
                                                                   ops.colsum(dzl, out=gb)))
                     # dX of this block = dZ of the previous one when its act' rides in the epilogue; its column
                     # sums (the previous block's bias gradient) then come out of the same launch
@@ -417,6 +420,8 @@ class FusedTrainer:
                     db_done = False
                 dz_ready = fuse_prev
                 keep.append(dh)
+            if skp is not None:
+                skp.finish()
             # the bias-gradient finishes: beside the first launch of the embedding reduction when that is fused
             if self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse":
                 pending_colsum = csp.hand_over()

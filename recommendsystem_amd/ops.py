@@ -152,7 +152,8 @@ OPT_CODES = {"SGD": 0, "Adam": 1, "AdamW": 2, "Adagrad": 3}
 # GEMM
 # ---------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
-         mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None) -> torch.Tensor:
+         mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None,
+         defer_reduce=None) -> torch.Tensor:
     """C = epi(op(A) op(B)) in fp32 on the matrix cores.
 
     a_mc=False: a is [M, K];  a_mc=True: a is [K, M] (used as its transpose).
@@ -160,6 +161,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     colsum_part: a ColsumParts collector; the GEMM leaves per-wave-row column sums of C in a scratch buffer and
     registers (buffer, rows, N, destination) with it -- ColsumParts.finish() adds them up in one launch for
     every registered GEMM (the bias gradients of the dZ's the backward chain produces).
+    defer_reduce: a SplitKParts collector; a product whose reduction is split leaves its slabs there and `out` is
+    only valid after the collector's finish() (one launch for all of them).
     """
     _chk(a, torch.float32, "a")
     _chk(b, torch.float32, "b")
@@ -187,6 +190,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
         if splitk <= 0:
             splitk = sk.value
     ws = ws or default_workspace(a.device)
+    if (defer_reduce is not None and splitk > 1 and splitk * 32 <= K and bias is None and act == 0 and mulsrc is None
+            and colsum_part is None and out.is_contiguous()):
+        # slabs only; `out` is written by defer_reduce.finish()
+        wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
+        wbuf = defer_reduce.buffer(wbytes // 4)
+        call("rs_gemm_f32_slabs", int(a_mc), int(b_nc), M, N, K, ptr(a), a.shape[1], ptr(b), b.shape[1], int(tile),
+             int(splitk), ptr(wbuf), wbytes, stream())
+        defer_reduce.add(wbuf, out, M * N, splitk)
+        return out
     wbuf, wbytes = None, 0
     if splitk > 1:
         wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
@@ -205,6 +217,35 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     if colsum_part is not None and part is None:
         colsum(out, out=colsum_part.take_destination(), ws=ws)        # split reduction: separate column-sum launch
     return out
+
+
+class SplitKParts:
+    """Collects split-K products whose slabs wait in their own workspace buffers and reduces them in one launch.
+
+    Usage: p = SplitKParts(ws); ops.gemm(..., out=dW, defer_reduce=p); ...; p.finish().  A product whose plan does
+    not split is computed directly."""
+
+    def __init__(self, ws: "Workspace"):
+        self.ws = ws
+        self._items = []            # (slab buffer, out, M*N, splitk)
+
+    def buffer(self, numel: int) -> torch.Tensor:
+        return self.ws.get(f"gemm_slabs_{len(self._items)}", numel)
+
+    def add(self, wbuf, out, total: int, splitk: int):
+        self._items.append((wbuf, out, int(total), int(splitk)))
+
+    def finish(self):
+        import ctypes as C
+        items, self._items = self._items, []
+        for i in range(0, len(items), 8):
+            grp = items[i:i + 8]
+            k = len(grp)
+            W = (C.c_void_p * k)(*[g[0].data_ptr() for g in grp])
+            O = (C.c_void_p * k)(*[g[1].data_ptr() for g in grp])
+            T = (C.c_longlong * k)(*[g[2] for g in grp])
+            S = (C.c_int * k)(*[g[3] for g in grp])
+            call("rs_splitk_reduce_multi", W, O, T, S, k, stream())
 
 
 class ColsumParts:

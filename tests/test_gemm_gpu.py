@@ -156,3 +156,31 @@ def test_gemm_colsum_byproduct(M, N, K, tile):
         parts.finish()
         ref = ops.gemm(A, W, b_nc=True, tile=tile, splitk=2).double()
         assert ((cs2.double() - ref.sum(0)).abs() <= 1e-6 * ref.abs().sum(0) + 1e-30).all()
+
+
+def test_deferred_splitk_products_reduce_in_one_launch():
+    """Weight-gradient shaped products leave their slabs behind; one rs_splitk_reduce_multi finishes all of them with
+    the bits of the immediate form (same slabs, same slab order)."""
+    from recommendsystem_amd import ops
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 96, 4096), (64, 130, 2048), (33, 7, 4096)]        # (M, N, K); the last one has unaligned outputs
+    ws = ops.Workspace(torch.device(DEV))
+    coll = ops.SplitKParts(ws)
+    outs, wants = [], []
+    for M, N, K in shapes:
+        a = torch.randn(K, M, generator=g).to(DEV)
+        b = torch.randn(K, N, generator=g).to(DEV)
+        wants.append(ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=4))
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=4, out=out, defer_reduce=coll)
+        outs.append(out)
+    assert all(torch.isnan(o).all() for o in outs)                    # nothing written before finish()
+    coll.finish()
+    for o, w in zip(outs, wants):
+        assert torch.equal(o, w)
+    # a product that does not split is computed at once
+    a, b = torch.randn(64, 32, generator=g).to(DEV), torch.randn(64, 48, generator=g).to(DEV)
+    out = ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=1, defer_reduce=coll)
+    assert torch.equal(out, ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=1))
+    coll.finish()
