@@ -9,7 +9,7 @@ What it does: imports the reference's live modules (model.utils.Layers,
 model.utils.BaseModel), aliases the stale package name ``models`` to ``model``
 so the nine model files import, calls their methods on stub ``self`` objects,
 and saves inputs/outputs as small arrays.  Two harness-side accommodations of
-reference defects, both documented in DESIGN.md:
+reference defects:
 
 * ``Embedding_layer.forward(scalar_only=True)`` raises KeyboardInterrupt
   (model/utils/Layers.py:154-157), so LR vectors are produced from the
