@@ -100,8 +100,9 @@ def run_cpu(outdir):
         keep = (all_idx[r].t().reshape(-1) > 0)
         G.index_add_(0, fl[keep], all_g[r][keep])
         G1.index_add_(0, fl[keep], all_d[r].repeat_interleave(F)[keep])
-    torch.testing.assert_close(k.own_grad, spec.shard_table(G), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(k.own_grad1, spec.shard_table(G1.view(-1, 1)).view(-1), rtol=1e-5, atol=1e-6)
+    # (sums of up to N*B terms per row, added in a different order than index_add_'s)
+    torch.testing.assert_close(k.own_grad, spec.shard_table(G), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(k.own_grad1, spec.shard_table(G1.view(-1, 1)).view(-1), rtol=1e-4, atol=2e-5)
     sq = part[:1].clone()
     comm.all_reduce(sq)
     torch.testing.assert_close(sq[0], (G ** 2).sum() + (G1 ** 2).sum(), rtol=1e-5, atol=0)

@@ -31,7 +31,7 @@ def test_shard_spec_partitions_every_row_once():
         assert specs[0].bucket_capacity(4096) <= 4096
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_exchange_protocol_gloo(world, tmp_path):
     codes, outs = run_ranks(world, ["cpu", str(tmp_path)])
     assert codes == [0] * world, "\n".join(outs)
