@@ -302,6 +302,24 @@ def main():
                         "unit": "GB/s", "frac": ent["frac_of_peak"], "algorithmic_bytes_per_launch": a["work"],
                         "avg_us": ent["avg_us"]}
 
+    # K3 (sparse backward + touched-rows update) against the HBM roofline: algorithmic bytes = per entry the index and
+    # the gradient row (+ the embedding row re-read where the FM term is formed on the fly), per distinct row the
+    # optimizer's reads and writes of w (and its moments), over the separately timed sort + reduce + update launches.
+    roofline_hbm_scatter = None
+    k3_us = sum(per_step.get(k, 0.0) for k in ("rs_sparse_bwd_sort", "rs_sparse_bwd_reduce", "rs_sparse_update"))
+    if not use_dist and fused_kind and args.mode == "sparse" and k3_us > 0 and hasattr(eng, "plan"):
+        plan = eng.plan(args.batch)
+        uniq = int(plan.counts()[:, 2].sum().item())             # distinct non-padding rows of the last batch
+        d_emb = eng.d if eng.has_emb else 0
+        per_entry = 8 + 4 * d_emb + (4 * d_emb if eng.has_fm else 0) + (4 if eng.has_lr else 0)
+        n_state = {"SGD": 2, "Adagrad": 4}.get(args.optimizer, 6)
+        per_row = n_state * 4 * (d_emb + (1 if eng.has_lr else 0))
+        k3_bytes = args.batch * len(vocab) * per_entry + uniq * per_row
+        roofline_hbm_scatter = {"bound": "hbm", "kernel": "K3: field_sort + chunk_reduce + segment_finalize + sparse_update",
+                                "achieved": round(k3_bytes / k3_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(k3_bytes / k3_us / 1e3 / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_step": k3_bytes, "distinct_rows": uniq, "us_per_step": round(k3_us, 1)}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         cpu = cpu_baseline(args, rec, hidden, idxs, labs)
@@ -323,7 +341,8 @@ def main():
                        "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": "single GPU" if world == 1 else f"dp{world} + row-sharded tables (RCCL all-to-all)"},
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_hbm_scatter": roofline_hbm_scatter,
+            "cpu_baseline": cpu,
             "kernel_us_per_step": {k: round(v, 1) for k, v in per_step.items()},
             "kernels": kernels[:12], "final_loss": final_loss,
         }
