@@ -673,6 +673,23 @@ __global__ __launch_bounds__(256) void nfm_bi_bwd_kernel(const float* __restrict
 // Register forms of the two NFM kernels for D <= 64*T: V sits in LDS once per workgroup, a lane's T elements of a
 // sample are loaded up front, and (backward) its T*KT dV accumulators stay in registers.  Same arithmetic and
 // summation orders as the kernels above.
+// Row n of the LDS copy of V: 16-byte reads when the row is exactly KT (>= 4) floats, else scalar reads.
+template <int KT>
+__device__ __forceinline__ void nfm_load_v(const float* sm, int n, int K, float (&vr)[KT]) {
+    if constexpr (KT >= 4) {
+        if (K == KT) {
+#pragma unroll
+            for (int c4 = 0; c4 < KT / 4; ++c4) {
+                const float4 t = reinterpret_cast<const float4*>(sm + n * KT)[c4];
+                vr[4 * c4] = t.x; vr[4 * c4 + 1] = t.y; vr[4 * c4 + 2] = t.z; vr[4 * c4 + 3] = t.w;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) vr[c] = c < K ? sm[n * K + c] : 0.f;
+}
+
 template <int T, int KT>
 __global__ __launch_bounds__(256) void nfm_bi_fwd_reg_kernel(const float* __restrict__ E, const float* __restrict__ V, int B,
                                                              int D, int K, float* __restrict__ out,
@@ -695,12 +712,13 @@ __global__ __launch_bounds__(256) void nfm_bi_fwd_reg_kernel(const float* __rest
         for (int i = 0; i < T; ++i) {
             const int n = lane + 64 * i;
             if (n < D) {
+                float vr[KT];
+                nfm_load_v<KT>(sm, n, K, vr);
 #pragma unroll
                 for (int c = 0; c < KT; ++c) {
                     if (c < K) {
-                        const float v = sm[n * K + c];
-                        s[c] = fmaf(e[i], v, s[c]);
-                        q[c] = fmaf(e[i] * e[i], v * v, q[c]);
+                        s[c] = fmaf(e[i], vr[c], s[c]);
+                        q[c] = fmaf(e[i] * e[i], vr[c] * vr[c], q[c]);
                     }
                 }
             }
@@ -749,10 +767,12 @@ __global__ __launch_bounds__(256) void nfm_bi_bwd_reg_kernel(const float* __rest
             const int n = lane + 64 * i;
             if (n < D) {
                 float de = 0.f;
+                float vr[KT];
+                nfm_load_v<KT>(sm, n, K, vr);
 #pragma unroll
                 for (int c = 0; c < KT; ++c) {
                     if (c < K) {
-                        const float v = sm[n * K + c];
+                        const float v = vr[c];
                         de = fmaf(g[c], s[c] * v - e[i] * v * v, de);
                         acc[i][c] = fmaf(g[c] * e[i], s[c] - e[i] * v, acc[i][c]);
                     }
@@ -1728,7 +1748,7 @@ int rs_dcn_cross_fwd(const float* x0, const float* w, const float* bias, int B, 
     RS_CHECK_ARG(x0 && w && bias && out, "rs_dcn_cross_fwd: null argument");
     const int T = dcn_reg_T(D);
     if (T && L <= 4 && (size_t)2 * L * D * sizeof(float) <= LDS_LIMIT) {
-        const int grid = rs_cdiv(B, 4) < 1024 ? rs_cdiv(B, 4) : 1024;
+        const int grid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
         const size_t rlds = (size_t)2 * L * D * sizeof(float);
 #define RS_DCN_F(TT, LL) hipLaunchKernelGGL((dcn_cross_fwd_reg_kernel<TT, LL>), dim3(grid), dim3(256), rlds, stream, x0, w, bias, B, D, out, S)
         RS_DCN_DISPATCH(RS_DCN_F, T, L)
@@ -1785,7 +1805,7 @@ int rs_nfm_bi_fwd(const float* E, const float* V, int B, int D, int K, float* ou
         const int T = dcn_reg_T(D), KT = nfm_KT(K);
         const size_t rlds = (size_t)D * K * sizeof(float);
         if (T && rlds <= LDS_LIMIT) {
-            const int grid = rs_cdiv(B, 4) < 1024 ? rs_cdiv(B, 4) : 1024;
+            const int grid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
 #define RS_NFM_FR(TT, KK) hipLaunchKernelGGL((nfm_bi_fwd_reg_kernel<TT, KK>), dim3(grid), dim3(256), rlds, stream, E, V, B, D, K, out, s_out)
             RS_NFM_FWD_DISPATCH(RS_NFM_FR, T, KT)
 #undef RS_NFM_FR
