@@ -618,7 +618,7 @@ class DistributedSparseTrainer(SparseTrainer):
                 ex.k.update(self.opt, self.hyper, self.scal, st["shard"], st["m"], st["v"], None, None, None)
             else:
                 ex.k.update(self.opt, self.hyper, self.scal, None, None, None, st["shard"], st["m"], st["v"])
-        self.last = {"records": cap.records}
+        self.last = {"records": cap.records, "direct_grads": len(cap._sunk)}
         return loss.detach()
 
     def sync_to_model(self):

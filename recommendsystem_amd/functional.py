@@ -68,11 +68,17 @@ class TableCapture:
 
     active = None
 
-    def __init__(self, provider=None):
+    def __init__(self, provider=None, grad_sinks=None, splitk=None):
         # provider: object with emb(idx, holder) -> [B, F, d] and lr_terms(idx, holder) -> [B, F] (the per-field
         # 1-dim values) that fetches rows from somewhere else than the local stacked table (row-sharded tables)
+        # grad_sinks: id(parameter) -> zero-initialised gradient tensor the MLP-block backward writes into directly
+        # (instead of returning a gradient for autograd to add); splitk: an ops.SplitKParts that collects the
+        # split-K slabs of those weight gradients -- the trainer calls its finish() once after backward()
         self.records = []
         self.provider = provider
+        self.grad_sinks = grad_sinks or {}
+        self.splitk = splitk
+        self._sunk = set()
         self._idx = {}           # (id of the batch dict, columns) -> (batch dict, index matrix): one stack per forward
 
     def index_matrix(self, x, cols, build):
@@ -93,6 +99,15 @@ class TableCapture:
     def __exit__(self, *exc):
         TableCapture.active = None
         return False
+
+    def sink(self, pid):
+        """The gradient destination of parameter `pid` on its first use in this pass (a parameter that appears twice
+        in the graph gets its further contributions through autograd's accumulation)."""
+        t = self.grad_sinks.get(pid)
+        if t is None or pid in self._sunk:
+            return None
+        self._sunk.add(pid)
+        return t
 
     def record(self, kind, holder, idx, out):
         out.requires_grad_(True)
@@ -202,7 +217,8 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
     return c.h, c
 
 
-def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0):
+def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0,
+                  defer_reduce=None):
     """Backward of one block.  Returns dict(dx, dW, db, dgamma, dbeta, dslope).
 
     dz_ready: `dh` already is dL/dz (the caller fused act' into the GEMM that produced it).
@@ -227,7 +243,7 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             dz, out["dgamma"], out["dbeta"] = ops.bn_bwd(dh, hh, c.xhat, fus, c.gamma, c.var, c.eps)
         else:
             dz, out["dgamma"], out["dbeta"] = ops.ln_bwd(dh, hh, c.xhat, c.rstd, c.gamma, fus)
-    out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out)
+    out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
     out["db"] = ops.colsum(dz, out=db_out)
     out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act) if need_dx else None
     out["dz"] = dz
@@ -240,12 +256,21 @@ class _MLPBlockFn(torch.autograd.Function):
         h, c = mlp_block_fwd(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps)
         ctx.c = c
         ctx.has = (gamma is not None, slope is not None)
+        ctx.pids = (id(W), id(b) if b is not None else None)
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0])
-        return (r["dx"], r["dW"], r["db"], r["dgamma"], r["dbeta"], r["dslope"], None, None, None, None, None, None)
+        cap = TableCapture.active
+        sW = sb = defer = None
+        if cap is not None and cap.grad_sinks:
+            sW = cap.sink(ctx.pids[0])
+            sb = cap.sink(ctx.pids[1]) if ctx.pids[1] is not None else None
+            defer = cap.splitk if sW is not None else None
+        r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0], dW_out=sW, db_out=sb, defer_reduce=defer)
+        # gradients written into their sinks are not handed to autograd a second time
+        return (r["dx"], None if sW is not None else r["dW"], None if sb is not None else r["db"], r["dgamma"], r["dbeta"],
+                r["dslope"], None, None, None, None, None, None)
 
 
 def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):

@@ -235,12 +235,20 @@ class SparseTrainer:
         self.flat_g_ext.zero_()
         for p, gv in zip(self.dense, self._gviews):
             p.grad = gv                              # autograd accumulates into the flat buffer in place
-        with Fn.TableCapture(provider) as cap:
+        # MLP blocks write weight / bias gradients straight into the flat buffer (no autograd accumulation launch per
+        # parameter) and leave their split-K slabs to one reducing launch; with an L2 term autograd also adds into
+        # those views, so the plain route is kept there
+        direct = not m.net_regular
+        sinks = {id(p): gv for p, gv in zip(self.dense, self._gviews)} if direct else None
+        splitk = ops.SplitKParts(ops.default_workspace(self.device)) if direct else None
+        with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk) as cap:
             out = m.forward(inputs)
             loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
                 loss = loss + m.regularization_loss()
             (loss if grad_scale == 1.0 else loss * grad_scale).backward()
+            if splitk is not None:
+                splitk.finish()
         return cap, loss
 
     def _step_impl(self, inputs, y) -> torch.Tensor:
@@ -288,5 +296,5 @@ class SparseTrainer:
                             table=e["w"] if e else None, m=e["m"] if e else None, v=e["v"] if e else None,
                             table1=flat(l["w"]) if l else None, m1=flat(l["m"]) if l else None,
                             v1=flat(l["v"]) if l else None)
-        self.last = {"records": cap.records}
+        self.last = {"records": cap.records, "direct_grads": len(cap._sunk)}
         return loss.detach()

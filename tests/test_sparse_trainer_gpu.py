@@ -56,6 +56,9 @@ def test_sparse_step_matches_dense_oracle(use_graph, kind, optimizer, steps, kw)
             atol = 5e-5 if optimizer in ("Adam", "Adagrad") else 5e-6
             torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
     assert eng.step_count.item() == steps
+    if not use_graph and kind in ("pnn", "dcn", "nfm", "widedeep"):
+        # the MLP blocks wrote their weight and bias gradients straight into the flat buffer
+        assert eng.last["direct_grads"] >= 2 * len(kw["hidden_dim_list"])
 
 
 def test_sparse_step_rejects_embedding_regulariser():
