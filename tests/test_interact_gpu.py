@@ -262,3 +262,20 @@ def test_unsupported_shapes_raise():
                     torch.zeros(4, device=DEV), torch.zeros(5, device=DEV), torch.zeros(1, device=DEV))
     with pytest.raises(RSError):
         ops.nfm_bi_fwd(torch.zeros(2, 8, device=DEV), torch.zeros(8, 17, device=DEV))
+
+
+def test_wide_row_limits_raise():
+    from recommendsystem_amd import ops
+    from recommendsystem_amd._lib import RSError
+    layout = ops.FieldLayout([5, 6, 7], DEV)
+    with pytest.raises(RSError):
+        ops.FFMPlan(layout, cap=8, d=3)                      # rows must be float4-divisible
+    with pytest.raises(RSError):
+        ops.FFMPlan(ops.FieldLayout([4] * 40, DEV), cap=8, d=32)   # 40 * 32 floats per row > 1024
+    with pytest.raises(RSError):
+        ops.WidePlan(layout, cap=8, W=1028)
+    wp = ops.WidePlan(layout, cap=8, W=12)
+    with pytest.raises(RSError):
+        wp.reduce_wide(torch.zeros(wp.n_partials_wide, device=DEV), torch.zeros(24, 16, device=DEV))   # wrong width
+    with pytest.raises(RSError):
+        ops.ffm_rows_fwd(torch.zeros(2, 3, 10, device=DEV), 4)                                           # not F*d wide
