@@ -231,13 +231,15 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
  * sum-of-squares partials of a dense buffer (the flat gradient of the dense parameters): both are pieces of the one
  * global norm of clip_grad_norm_ (BaseModel.py:148).  cs_*: up to 8 column-sum finishes (the arguments of
  * rs_colsum_finish_multi; cs_count may be 0) that run beside its first launch -- the bias gradients of the dense
- * backward, which may lie inside `dense`. */
+ * backward, which may lie inside `dense`; sk_*: likewise up to 8 split-K reductions (the arguments of
+ * rs_splitk_reduce_multi) -- its weight gradients. */
 int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                                float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
-                               float* const* cs_out, int cs_count, rs_stream_t stream);
+                               float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                               const long long* sk_total, const int* sk_splitk, int sk_count, rs_stream_t stream);
 /* The same reduction for rows of W floats (W % 4 == 0, W <= 1024; field-aware FFM rows on the row-sharded path):
  * rowgrad[f, s, :] = sum of gout[sorted_src[q], :] over the entries of segment s, in ascending order; chunk_part
  * [F, cap, W] is scratch; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.  The plan's window L

@@ -43,7 +43,8 @@ _SIGS = {
                              c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_sparse_bwd_reduce_sumsq": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, I,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     "rs_sparse_dense_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_stream],
     "rs_sparse_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

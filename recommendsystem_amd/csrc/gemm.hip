@@ -23,6 +23,7 @@
 // the other LDS buffer after them (one barrier per k-tile).
 #include "common.h"
 #include "colsum_finish.h"
+#include "splitk_multi.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -683,40 +684,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     }
 }
 
-// The same for several deferred products in one launch (no epilogue): product p owns workgroups
-// [first_block[p], first_block[p+1]); float4 where the buffers allow it.
-constexpr int SK_MAX = 8;
-struct SplitKMultiArgs {
-    const float* ws[SK_MAX]; float* C[SK_MAX];
-    long long total[SK_MAX];
-    int splitk[SK_MAX], vec[SK_MAX], first_block[SK_MAX + 1];
-    int count;
-};
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(SplitKMultiArgs a) {
-    int p = 0;
-    while (p + 1 < a.count && (int)blockIdx.x >= a.first_block[p + 1]) ++p;
-    const int nb = a.first_block[p + 1] - a.first_block[p], b = (int)blockIdx.x - a.first_block[p];
-    const long long total = a.total[p], stride = (long long)nb * 256;
-    const float* ws = a.ws[p];
-    float* C = a.C[p];
-    const int sk = a.splitk[p];
-    if (a.vec[p]) {
-        const long long t4 = total / 4;
-        for (long long e = (long long)b * 256 + threadIdx.x; e < t4; e += stride) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < sk; ++z) {
-                const float4 t = reinterpret_cast<const float4*>(ws + z * total)[e];
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            reinterpret_cast<float4*>(C)[e] = v;
-        }
-    } else {
-        for (long long e = (long long)b * 256 + threadIdx.x; e < total; e += stride) {
-            float v = 0.f;
-            for (int z = 0; z < sk; ++z) v += ws[z * total + e];
-            C[e] = v;
-        }
-    }
+    splitk_reduce_multi_body(a, blockIdx.x);
 }
 
 template <int BM, int BN, bool A_MC, bool B_NC, bool VA, bool VB>
@@ -976,18 +945,8 @@ int rs_splitk_reduce_multi(const float* const* ws, float* const* C, const long l
     if (count == 0) return RS_OK;
     RS_CHECK_ARG(ws && C && total && splitk, "rs_splitk_reduce_multi: null argument");
     SplitKMultiArgs a;
-    int blocks = 0;
-    for (int p = 0; p < count; ++p) {
-        RS_CHECK_ARG(ws[p] && C[p] && total[p] > 0 && splitk[p] > 0, "rs_splitk_reduce_multi: bad product %d", p);
-        a.ws[p] = ws[p]; a.C[p] = C[p]; a.total[p] = total[p]; a.splitk[p] = splitk[p];
-        a.vec[p] = (aligned16(ws[p]) && aligned16(C[p]) && total[p] % 4 == 0) ? 1 : 0;
-        a.first_block[p] = blocks;
-        const long long units = a.vec[p] ? total[p] / 4 : total[p];
-        long long b = (units + 255) / 256;
-        blocks += (int)(b > 1024 ? 1024 : b);
-    }
-    a.first_block[count] = blocks;
-    a.count = count;
+    const int blocks = splitk_multi_fill(a, ws, C, total, splitk, count);
+    RS_CHECK_ARG(blocks >= 0, "rs_splitk_reduce_multi: bad product (null pointer, empty output or splitk < 1)");
     hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
     RS_CHECK_LAUNCH("rs_splitk_reduce_multi");
     return RS_OK;

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "colsum_finish.h"
 #include "gather_body.h"
+#include "splitk_multi.h"
 #include "plan.h"
 
 namespace {
@@ -316,14 +317,17 @@ __global__ __launch_bounds__(256) void chunk_reduce_kernel(ReduceArgs a) {
     chunk_reduce_body<VEC>(a, blockIdx.y, blockIdx.x);
 }
 
-// chunk_reduce for workgroups [0, F*wx) and, behind them, the finishing additions of the partial column sums the
-// dense backward left (bias gradients): independent work that waits for the same predecessors.
+// chunk_reduce for workgroups [0, F*wx) and, behind them, the finishing additions of the partial column sums
+// (bias gradients) and of the split-K slabs (weight gradients) the dense backward left: independent work that
+// waits for the same predecessors.
 template <int VEC>
-__global__ __launch_bounds__(256) void chunk_reduce_colsum_kernel(ReduceArgs a, int wx, ColsumFinishArgs cf) {
+__global__ __launch_bounds__(256) void chunk_reduce_colsum_kernel(ReduceArgs a, int wx, ColsumFinishArgs cf, int cs_blocks,
+                                                                  SplitKMultiArgs sk) {
     __shared__ float red[16][17];
     const int b = blockIdx.x, nsp = a.F * wx;
     if (b < nsp) chunk_reduce_body<VEC>(a, b / wx, b % wx);
-    else colsum_finish_body(cf, b - nsp, red);
+    else if (b < nsp + cs_blocks) colsum_finish_body(cf, b - nsp, red);
+    else splitk_reduce_multi_body(sk, b - nsp - cs_blocks);       // weight-gradient slabs of the dense backward
 }
 
 template <int VEC>
@@ -832,14 +836,16 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
 
 // rs_sparse_bwd_reduce plus, in the launch of its second phase, the sum-of-squares partials of a dense buffer
 // (dense_partials[0 .. n_dense_partials), one per extra workgroup) and, in the launch of its first phase, the
-// cs_count column-sum finishes of rs_colsum_finish_multi (cs_* as that entry point's arguments; cs_count may be 0).
-// The finished column sums may be part of `dense`: the second launch starts after the first has ended.
+// cs_count column-sum finishes of rs_colsum_finish_multi and the sk_count split-K reductions of rs_splitk_reduce_multi
+// (cs_* / sk_* as those entry points' arguments; the counts may be 0).  Their outputs may be part of `dense`: the
+// second launch starts after the first has ended.
 int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                                float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
-                               float* const* cs_out, int cs_count, hipStream_t stream) {
+                               float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                               const long long* sk_total, const int* sk_splitk, int sk_count, hipStream_t stream) {
     RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
     RS_CHECK_ARG(cs_count >= 0 && cs_count <= CF_MAX, "rs_sparse_bwd_reduce_sumsq: at most %d column-sum problems", CF_MAX);
     ColsumFinishArgs cf{};
@@ -848,6 +854,14 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
         RS_CHECK_ARG(cs_part && cs_rows && cs_n && cs_ld && cs_out, "rs_sparse_bwd_reduce_sumsq: null column-sum arrays");
         cs_blocks = colsum_finish_fill(cf, cs_part, cs_rows, cs_n, cs_ld, cs_out, cs_count);
         RS_CHECK_ARG(cs_blocks >= 0, "rs_sparse_bwd_reduce_sumsq: bad column-sum problem");
+    }
+    RS_CHECK_ARG(sk_count >= 0 && sk_count <= SK_MAX, "rs_sparse_bwd_reduce_sumsq: at most %d split-K products", SK_MAX);
+    SplitKMultiArgs sk{};
+    int sk_blocks = 0;
+    if (sk_count > 0) {
+        RS_CHECK_ARG(sk_ws && sk_out && sk_total && sk_splitk, "rs_sparse_bwd_reduce_sumsq: null split-K arrays");
+        sk_blocks = splitk_multi_fill(sk, sk_ws, sk_out, sk_total, sk_splitk, sk_count);
+        RS_CHECK_ARG(sk_blocks >= 0, "rs_sparse_bwd_reduce_sumsq: bad split-K product");
     }
     RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce_sumsq: dfm needs S and emb");
     RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce_sumsq: chunk_sum1/rowgrad1 mismatch");
@@ -863,14 +877,14 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     const int gx = rs_cdiv(cap, 256 / a.C);
     dim3 block(256), wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F), fgrid(F * gx + n_dense_partials);
     const int wx = (int)wgrid.x;
-    dim3 cgrid(F * wx + cs_blocks);
+    dim3 cgrid(F * wx + cs_blocks + sk_blocks);
     if (VEC == 4) {
-        if (cs_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<4>, cgrid, block, 0, stream, a, wx, cf);
+        if (cs_blocks + sk_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<4>, cgrid, block, 0, stream, a, wx, cf, cs_blocks, sk);
         else hipLaunchKernelGGL(chunk_reduce_kernel<4>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_sumsq_kernel<4>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
                            n_dense_partials);
     } else {
-        if (cs_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<1>, cgrid, block, 0, stream, a, wx, cf);
+        if (cs_blocks + sk_blocks) hipLaunchKernelGGL(chunk_reduce_colsum_kernel<1>, cgrid, block, 0, stream, a, wx, cf, cs_blocks, sk);
         else hipLaunchKernelGGL(chunk_reduce_kernel<1>, wgrid, block, 0, stream, a);
         hipLaunchKernelGGL(segment_finalize_sumsq_kernel<1>, fgrid, block, 0, stream, a, gx, dense, dense_n, dense_partials,
                            n_dense_partials);

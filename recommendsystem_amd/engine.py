@@ -279,7 +279,7 @@ class FusedTrainer:
     def _grad_scale(self) -> float:
         return 1.0
 
-    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None):
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None, splitk=None):
         """Row gradients of the touched rows; fills plan.partials[:plan.n_partials] with ||g||^2 partials.
         dense_partials: also leave the ||g||^2 partials of the flat dense gradient there (same launch)."""
         B = idx.shape[1]
@@ -289,7 +289,7 @@ class FusedTrainer:
                     emb=ctx["emb"].view(B * self.F, self.d) if self.has_fm else None,
                     dlr=dz if self.has_lr else None, Fdiv=self.F,
                     dense=self.flat_g if dense_partials is not None else None, dense_partials=dense_partials,
-                    colsum=colsum)
+                    colsum=colsum, splitk=splitk)
 
     def _reduce_dense_grads(self):
         """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
@@ -357,7 +357,7 @@ class FusedTrainer:
         # Critical chain on the main stream: dZ_l -> dX -> dZ_(l-1) ...; the weight/bias gradients of
         # a layer depend only on its dZ and run beside the chain on the side stream.
         gout = None
-        pending_colsum = None
+        pending_colsum = pending_splitk = None
         if self.blocks:
             cs = ctx["mlp"]
             dh = dz.view(B, 1)
@@ -420,12 +420,14 @@ class FusedTrainer:
                     db_done = False
                 dz_ready = fuse_prev
                 keep.append(dh)
-            if skp is not None:
-                skp.finish()
-            # the bias-gradient finishes: beside the first launch of the embedding reduction when that is fused
+            # the bias-gradient finishes and the weight-gradient split-K reduces: beside the first launch of the
+            # embedding reduction when that is fused
             if self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse":
                 pending_colsum = csp.hand_over()
+                pending_splitk = skp.hand_over() if skp is not None else None
             else:
+                if skp is not None:
+                    skp.finish()
                 csp.finish()
             gout = dh.view(B * self.F, self.d)
 
@@ -440,7 +442,7 @@ class FusedTrainer:
         fuse = self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"
         if fuse:
             self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p,
-                                 colsum=pending_colsum)
+                                 colsum=pending_colsum, splitk=pending_splitk)
         else:
             self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early)
 

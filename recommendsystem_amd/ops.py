@@ -235,17 +235,28 @@ class SplitKParts:
     def add(self, wbuf, out, total: int, splitk: int):
         self._items.append((wbuf, out, int(total), int(splitk)))
 
-    def finish(self):
+    @staticmethod
+    def _arrays(grp):
         import ctypes as C
+        k = len(grp)
+        W = (C.c_void_p * k)(*[g[0].data_ptr() for g in grp])
+        O = (C.c_void_p * k)(*[g[1].data_ptr() for g in grp])
+        T = (C.c_longlong * k)(*[g[2] for g in grp])
+        S = (C.c_int * k)(*[g[3] for g in grp])
+        return W, O, T, S, k
+
+    def finish(self):
         items, self._items = self._items, []
         for i in range(0, len(items), 8):
-            grp = items[i:i + 8]
-            k = len(grp)
-            W = (C.c_void_p * k)(*[g[0].data_ptr() for g in grp])
-            O = (C.c_void_p * k)(*[g[1].data_ptr() for g in grp])
-            T = (C.c_longlong * k)(*[g[2] for g in grp])
-            S = (C.c_int * k)(*[g[3] for g in grp])
-            call("rs_splitk_reduce_multi", W, O, T, S, k, stream())
+            call("rs_splitk_reduce_multi", *self._arrays(items[i:i + 8]), stream())
+
+    def hand_over(self):
+        """The pending products as the (ws, out, total, splitk, count) argument arrays of one reducing launch, for a
+        consumer that runs them inside a launch of its own; anything beyond eight products is reduced here."""
+        items, self._items = self._items, []
+        for i in range(8, len(items), 8):
+            call("rs_splitk_reduce_multi", *self._arrays(items[i:i + 8]), stream())
+        return self._arrays(items[:8]) if items else None
 
 
 class ColsumParts:
@@ -538,10 +549,10 @@ class SparsePlan:
              stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
-               Fdiv=None, dense=None, dense_partials=None, colsum=None):
+               Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None):
         """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats).  dense / dense_partials: also
         write the sum-of-squares partials of the flat buffer `dense` (one per element of dense_partials) from the
-        same launch.  colsum: ColsumParts.hand_over() -- those finishes run beside the first launch."""
+        same launch.  colsum / splitk: ColsumParts.hand_over() / SplitKParts.hand_over() -- those run beside the first launch."""
         if norm_partials.numel() < self.n_partials:
             raise RSError("sparse backward: norm_partials too small")
         for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
@@ -552,9 +563,10 @@ class SparsePlan:
             call("rs_sparse_bwd_reduce_sumsq", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm),
                  ptr(S), ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1),
                  ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense), dense.numel(),
-                 ptr(dense_partials), dense_partials.numel(), *(colsum or (None, None, None, None, None, 0)), stream())
+                 ptr(dense_partials), dense_partials.numel(), *(colsum or (None, None, None, None, None, 0)),
+                 *(splitk or (None, None, None, None, 0)), stream())
             return
-        if colsum is not None:
+        if colsum is not None or splitk is not None:
             raise RSError("sparse backward: column-sum finishes ride only with the dense-norm form of the reduction")
         call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
