@@ -111,6 +111,7 @@ _PLAIN = {
     "rs_colsum_workspace_bytes": (SZ, [I, I]),
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_sort_max_entries": (I, []),
+    "rs_sort_two_level": (I, [I]),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),
     "rs_act_bwd_num_partials": (I, [L]),

@@ -68,10 +68,147 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int
     return base + inc - v;
 }
 
+// ---- stable LSD radix sort of the 1024*ITEMS items in buf, DB key bits per pass ---------------------
+// Items are taken striped (item j of thread t is element j*1024 + t), so the 64 lanes of a wave hold a
+// contiguous run of elements: one ballot per digit bit gives, for every digit value, the run's count
+// (lanes 0..NB-1 each build the mask of "their" value) and every lane's rank inside the run; an exclusive
+// scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that NB * runs = 1024.
+template <int ITEMS>
+__device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scratch, int nbits) {
+    constexpr int DB = ITEMS == 1 ? 6 : (ITEMS == 2 ? 5 : (ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2)));
+    constexpr int NB = 1 << DB;
+    constexpr int G = 16 * ITEMS;                 // runs of 64 elements
+    static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
+    const int t = threadIdx.x;
+    int* cnt = scratch + 32;                      // [NB][G]
+    const int lane = t & 63, w = t >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int bit = 0; bit < nbits; bit += DB) {
+        const int sh = 32 + bit;
+        unsigned long long x[ITEMS], mk[ITEMS];
+        int dg[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            x[j] = buf[j * SORT_THREADS + t];
+            const int dgt = (int)((x[j] >> sh) & (unsigned long long)(NB - 1));
+            unsigned long long own = ~0ull, mine = ~0ull;      // mask of my digit / of digit value `lane`
+#pragma unroll
+            for (int k = 0; k < DB; ++k) {
+                const unsigned long long mb = __ballot((dgt >> k) & 1);
+                own &= ((dgt >> k) & 1) ? mb : ~mb;
+                mine &= ((lane >> k) & 1) ? mb : ~mb;
+            }
+            if (lane < NB) cnt[lane * G + j * 16 + w] = __popcll(mine);
+            dg[j] = dgt;
+            mk[j] = own;
+        }
+        __syncthreads();
+        const int v = cnt[t];
+        int tot_unused;
+        const int ex = block_excl_scan(v, scratch, &tot_unused);
+        cnt[t] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int rank = cnt[dg[j] * G + j * 16 + w] + __popcll(mk[j] & lt);
+            buf[rank] = x[j];
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int key_bits(long long vocab) {
+    int nbits = 1;
+    const unsigned long long vmax = (unsigned long long)(vocab - 1);
+    while ((vmax >> nbits) != 0 && nbits < 32) ++nbits;
+    return nbits;
+}
+
+// ---- segmentation of the n sorted items in buf: heads of runs of equal keys, chunk heads every L sorted
+// positions; writes the plan arrays of field f.  Items are taken striped as in the radix passes, so every wave
+// holds 64 consecutive sorted positions: ballots give the heads before a lane inside its run of 64, one scan over
+// the 16*ITEMS run totals gives the heads before the run, and every plan array is written with consecutive
+// addresses per wave ------------------------------------------------------------------------------------------
+// `src` holds the field's sorted list (LDS or global), indexed by sorted position; the workgroup covers positions
+// pos0 .. pos0 + 1024*ITEMS.  prior / prior_pads: heads | chunk heads << 16 and padding entries before pos0;
+// the workgroup with `last` set writes the end marks and the counts.
+template <int ITEMS>
+__device__ __forceinline__ void segment_tail(const SortArgs& a, int f, const unsigned long long* src, int* scratch, int n,
+                                             int pos0 = 0, int prior = 0, int prior_pads = 0, bool last = true) {
+    constexpr int RUNS = 16 * ITEMS;
+    static_assert(RUNS <= SORT_THREADS, "one run total per thread");
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int* run_heads = scratch + 32;                // [RUNS] heads | chunk heads << 16
+    int* run_pads = run_heads + RUNS;             // [RUNS]
+    unsigned lo[ITEMS], key[ITEMS];
+    int st[ITEMS];                                // bit 0 head, bit 1 chunk head, bit 2 padding, bits 8.. / 16..: heads / chunk heads before the lane in its run
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = pos0 + j * SORT_THREADS + t;
+        const unsigned long long e = i < n ? src[i] : ~0ull;
+        lo[j] = (unsigned)(e & 0xFFFFFFFFull);
+        key[j] = (unsigned)(e >> 32);
+        const bool valid = i < n;
+        const bool pad = valid && key[j] == 0u;
+        const bool live = valid && !pad;
+        const bool head = live && (i == 0 || (unsigned)(src[i - 1] >> 32) != key[j]);
+        const bool chead = live && (head || (i % a.L == 0));
+        const unsigned long long hb = __ballot(head), cb = __ballot(chead), pb = __ballot(pad);
+        if (lane == 0) {
+            run_heads[j * 16 + w] = __popcll(hb) | (__popcll(cb) << 16);
+            run_pads[j * 16 + w] = __popcll(pb);
+        }
+        st[j] = (head ? 1 : 0) | (chead ? 2 : 0) | (pad ? 4 : 0) | (__popcll(hb & lt) << 8) | (__popcll(cb & lt) << 16);
+    }
+    __syncthreads();
+    const int rh = t < RUNS ? run_heads[t] : 0, rp = t < RUNS ? run_pads[t] : 0;
+    int tot, totpad;
+    const int ex = block_excl_scan(rh, scratch, &tot) + prior;
+    (void)block_excl_scan(rp, scratch, &totpad);
+    tot += prior;
+    totpad += prior_pads;
+    __syncthreads();
+    if (t < RUNS) run_heads[t] = ex;
+    __syncthreads();
+    const int n_seg = tot & 0xFFFF, n_chunk = tot >> 16;
+    int* sorted_src = a.sorted_src + (long long)f * a.cap;
+    int* entry_chunk = a.entry_chunk + (long long)f * a.cap;
+    int* entry_seg = a.entry_seg + (long long)f * a.cap;
+    int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
+    int* seg_row = a.seg_row + (long long)f * a.cap;
+    int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
+    const int roff = (int)a.row_offset[f];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = pos0 + j * SORT_THREADS + t;
+        if (i < n) {
+            const int base = run_heads[j * 16 + w];
+            const int seg = (base & 0xFFFF) + ((st[j] >> 8) & 0xFF);      // heads before this position
+            const int chk = (base >> 16) + ((st[j] >> 16) & 0xFF);        // chunk heads before this position
+            sorted_src[i] = (int)lo[j];
+            if (st[j] & 1) {
+                seg_row[seg] = roff + (int)key[j];
+                seg_first_chunk[seg] = chk;
+            }
+            if (st[j] & 2) chunk_start[chk] = i;
+            const bool pad = (st[j] & 4) != 0;
+            entry_chunk[i] = pad ? -1 : chk + ((st[j] >> 1) & 1) - 1;
+            entry_seg[i] = pad ? -1 : seg + (st[j] & 1) - 1;
+        }
+    }
+    if (t == 0 && last) {
+        chunk_start[n_chunk] = n;
+        seg_first_chunk[n_seg] = n_chunk;
+        int* c = a.counts + f * 4;
+        c[0] = n; c[1] = n_chunk; c[2] = n_seg; c[3] = totpad;
+    }
+}
+
 template <int ITEMS>
 __device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*ITEMS]
-    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32]
+    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32] + [1024]
     const int t = threadIdx.x;
     constexpr int CAPB = SORT_THREADS * ITEMS;
 
@@ -91,119 +228,155 @@ __device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
     }
     for (int j = n + t; j < CAPB; j += SORT_THREADS) buf[j] = ~0ull;   // sentinels sort last
     __syncthreads();
+    radix_passes<ITEMS>(buf, scratch, key_bits(a.vocab[f]));
+    segment_tail<ITEMS>(a, f, buf, scratch, n);
+}
 
-    int nbits = 1;
-    {
-        unsigned long long vmax = (unsigned long long)(a.vocab[f] - 1);
-        while ((vmax >> nbits) != 0 && nbits < 32) ++nbits;
-    }
-    // ---- stable LSD radix sort, DB key bits per pass ----------------------------------------------
-    // Items are taken striped (item j of thread t is element j*1024 + t), so the 64 lanes of a wave hold a
-    // contiguous run of elements: one ballot per digit bit gives, for every digit value, the run's count
-    // (lanes 0..NB-1 each build the mask of "their" value) and every lane's rank inside the run; an exclusive
-    // scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that NB * runs = 1024.
-    {
-        constexpr int DB = ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2);
-        constexpr int NB = 1 << DB;
-        constexpr int G = 16 * ITEMS;                 // runs of 64 elements
-        static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
-        int* cnt = scratch + 32;                      // [NB][G]
-        const int lane = t & 63, w = t >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int bit = 0; bit < nbits; bit += DB) {
-            const int sh = 32 + bit;
-            unsigned long long x[ITEMS], mk[ITEMS];
-            int dg[ITEMS];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                x[j] = buf[j * SORT_THREADS + t];
-                const int dgt = (int)((x[j] >> sh) & (unsigned long long)(NB - 1));
-                unsigned long long own = ~0ull, mine = ~0ull;      // mask of my digit / of digit value `lane`
-#pragma unroll
-                for (int k = 0; k < DB; ++k) {
-                    const unsigned long long mb = __ballot((dgt >> k) & 1);
-                    own &= ((dgt >> k) & 1) ? mb : ~mb;
-                    mine &= ((lane >> k) & 1) ? mb : ~mb;
-                }
-                if (lane < NB) cnt[lane * G + j * 16 + w] = __popcll(mine);
-                dg[j] = dgt;
-                mk[j] = own;
-            }
-            __syncthreads();
-            const int v = cnt[t];
-            int tot_unused;
-            const int ex = block_excl_scan(v, scratch, &tot_unused);
-            cnt[t] = ex;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int rank = cnt[dg[j] * G + j * 16 + w] + __popcll(mk[j] & lt);
-                buf[rank] = x[j];
-            }
-            __syncthreads();
+// ---- two-level form for one list per field (columnar batches) of more than 1024 entries -------------------
+// The single-workgroup sort keeps F of the 256 compute units busy and pays one pass per 2..4 key bits once a thread
+// holds 8 or 16 items.  Here the list is cut into tiles of TS = 1024*IT consecutive entries and three launches of
+// F * tiles workgroups each do the work:
+//   1. every tile is sorted by a workgroup of its own (few items per thread: 4..6 key bits per pass) -> tiles64
+//   2. every item finds its place in the merged order -- its place in its tile plus, by binary search, the items of
+//      every other tile that go before it; equal keys of an earlier tile go first, which keeps the sort stable and
+//      the order identical to the single-workgroup sort's -- and is written there -> merged64
+//   3. the segmentation runs per range of TS merged positions; a workgroup counts the heads before its range itself.
+// tiles64 / merged64: [F, cap] of key << 32 | gradient row.
+template <int IT>
+__device__ __forceinline__ void tile_sort_body(const SortArgs& a, int f, int tile, unsigned long long* tiles64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*IT]
+    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * IT);
+    constexpr int TS = SORT_THREADS * IT;
+    const int t = threadIdx.x;
+    const int cnt = a.sub_cnt[f], off = a.sub_off[f], pb = a.pay_base[f];
+    const long long V = a.vocab[f];
+    const int base = tile * TS;
+    const int nt = cnt - base < TS ? cnt - base : TS;          // entries of this tile (may be <= 0)
+    for (int j = t; j < TS; j += SORT_THREADS) {
+        unsigned long long e = ~0ull;
+        if (j < nt) {
+            long long k = a.keys[off + base + j];
+            if (k < 0 || k >= V) k = 0;
+            e = ((unsigned long long)(unsigned)k << 32) | (unsigned)(pb + (base + j) * a.pay_stride);
         }
+        buf[j] = e;
     }
-    unsigned long long it[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) it[j] = buf[t * ITEMS + j];
+    __syncthreads();
+    if (nt <= 0) return;                                       // uniform over the workgroup
+    radix_passes<IT>(buf, scratch, key_bits(V));
+    unsigned long long* dst = tiles64 + (long long)f * a.cap + base;
+    for (int j = t; j < nt; j += SORT_THREADS) dst[j] = buf[j];
+}
 
-    // ---- segmentation: heads of runs of equal keys, chunk heads every L sorted positions ----
-    int flags[ITEMS];
-    int packed = 0, padl = 0;
+// first position in the sorted tile (TS keys, sentinels last) whose key is >= key (UPPER: > key)
+template <int TS, bool UPPER>
+__device__ __forceinline__ int tile_bound(const unsigned* tile, unsigned key) {
+    int lo = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int i = t * ITEMS + j;
-        flags[j] = 0;
+    for (int step = TS / 2; step > 0; step >>= 1) {
+        const unsigned k = tile[lo + step - 1];
+        if (UPPER ? k <= key : k < key) lo += step;
+    }
+    const unsigned k = tile[lo];
+    if (UPPER ? k <= key : k < key) lo += 1;
+    return lo;
+}
+
+constexpr int SORT_MAX_TILES = 4;
+
+template <int IT>
+__device__ __forceinline__ void tile_rank_body(const SortArgs& a, int f, int q, int tiles, const unsigned long long* tiles64,
+                                               unsigned long long* merged64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned tkeys[];            // [tiles * TS]
+    constexpr int TS = SORT_THREADS * IT;
+    const int t = threadIdx.x;
+    const int n = a.sub_cnt[f];
+    if (q * TS >= n) return;                                                     // uniform over the workgroup
+    const unsigned long long* g = tiles64 + (long long)f * a.cap;
+    unsigned long long own[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int i = q * TS + j * SORT_THREADS + t;
+        own[j] = i < n ? g[i] : ~0ull;
+    }
+    for (int i = t; i < tiles * TS; i += SORT_THREADS) tkeys[i] = i < n ? (unsigned)(g[i] >> 32) : 0xFFFFFFFFu;
+    __syncthreads();
+    unsigned long long* dst = merged64 + (long long)f * a.cap;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int i = q * TS + j * SORT_THREADS + t;
         if (i < n) {
-            const unsigned k = (unsigned)(it[j] >> 32);
-            if (k == 0) { ++padl; }
-            else {
-                const bool head = (i == 0) || ((unsigned)(buf[i - 1] >> 32) != k);
-                const bool chead = head || (i % a.L == 0);
-                flags[j] = (head ? 1 : 0) | (chead ? 2 : 0);
-                packed += (head ? 1 : 0) + (chead ? (1 << 16) : 0);
+            const unsigned key = (unsigned)(own[j] >> 32);
+            int rank = j * SORT_THREADS + t;
+#pragma unroll
+            for (int o = 0; o < SORT_MAX_TILES; ++o) {
+                if (o == q || o >= tiles || o * TS >= n) continue;
+                rank += o < q ? tile_bound<TS, true>(tkeys + o * TS, key) : tile_bound<TS, false>(tkeys + o * TS, key);
             }
+            dst[rank] = own[j];
         }
     }
-    int tot, totpad;
-    int ex = block_excl_scan(packed, scratch, &tot);
-    (void)block_excl_scan(padl, scratch, &totpad);
-    const int n_seg = tot & 0xFFFF, n_chunk = tot >> 16;
-    int seg = (ex & 0xFFFF), chk = (ex >> 16);
-    int* sorted_src = a.sorted_src + (long long)f * a.cap;
-    int* entry_chunk = a.entry_chunk + (long long)f * a.cap;
-    int* entry_seg = a.entry_seg + (long long)f * a.cap;
-    int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
-    int* seg_row = a.seg_row + (long long)f * a.cap;
-    int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
-    const int roff = (int)a.row_offset[f];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int i = t * ITEMS + j;
-        if (i < n) {
-            sorted_src[i] = (int)(unsigned)(it[j] & 0xFFFFFFFFull);
-            if (flags[j] & 1) {
-                seg_row[seg] = roff + (int)(unsigned)(it[j] >> 32);
-                seg_first_chunk[seg] = chk;
-                ++seg;
-            }
-            if (flags[j] & 2) { chunk_start[chk] = i; ++chk; }
-            const bool pad = ((unsigned)(it[j] >> 32) == 0u);
-            entry_chunk[i] = pad ? -1 : chk - 1;
-            entry_seg[i] = pad ? -1 : seg - 1;
-        }
+}
+
+template <int IT>
+__device__ __forceinline__ void tile_tail_body(const SortArgs& a, int f, int q, int tiles, const unsigned long long* merged64) {
+    extern __shared__ __attribute__((aligned(16))) int tail_scratch[];           // [32] + [1024]
+    constexpr int TS = SORT_THREADS * IT;
+    const int t = threadIdx.x;
+    const int n = a.sub_cnt[f];
+    const bool last = q == tiles - 1;
+    if (q * TS >= n && !last) return;                                            // uniform over the workgroup
+    const unsigned long long* src = merged64 + (long long)f * a.cap;
+    const int lim = q * TS < n ? q * TS : n;
+    int hc = 0, pads = 0;                                                         // heads | chunk heads << 16 before the range
+    for (int i = t; i < lim; i += SORT_THREADS) {
+        const unsigned key = (unsigned)(src[i] >> 32);
+        const bool live = key != 0u;
+        const bool head = live && (i == 0 || (unsigned)(src[i - 1] >> 32) != key);
+        const bool chead = live && (head || (i % a.L == 0));
+        hc += (head ? 1 : 0) + (chead ? (1 << 16) : 0);
+        pads += live ? 0 : 1;
     }
-    if (t == 0) {
-        chunk_start[n_chunk] = n;
-        seg_first_chunk[n_seg] = n_chunk;
-        int* c = a.counts + f * 4;
-        c[0] = n; c[1] = n_chunk; c[2] = n_seg; c[3] = totpad;
+    int prior = 0, prior_pads = 0;
+    if (lim > 0) {
+        (void)block_excl_scan(hc, tail_scratch, &prior);
+        (void)block_excl_scan(pads, tail_scratch, &prior_pads);
+        __syncthreads();
     }
+    segment_tail<IT>(a, f, src, tail_scratch, n, q * TS, prior, prior_pads, last);
 }
 
 template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
     field_sort_body<ITEMS>(a, blockIdx.x);
+}
+
+template <int IT>
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(SortArgs a, int tiles, unsigned long long* tiles64) {
+    tile_sort_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles64);
+}
+
+template <int IT>
+__global__ __launch_bounds__(SORT_THREADS) void tile_rank_kernel(SortArgs a, int tiles, const unsigned long long* tiles64,
+                                                                 unsigned long long* merged64) {
+    tile_rank_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles, tiles64, merged64);
+}
+
+template <int IT>
+__global__ __launch_bounds__(SORT_THREADS) void tile_tail_kernel(SortArgs a, int tiles, const unsigned long long* merged64) {
+    tile_tail_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles, merged64);
+}
+
+// Level 1 of the two-level sort beside the gather (see sort_gather_kernel).
+template <int IT, int VEC>
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_gather_kernel(SortArgs a, int tiles, unsigned long long* tiles64,
+                                                                        GatherArgs ga) {
+    const int nsort = a.F * tiles;
+    if ((int)blockIdx.x < nsort) {
+        tile_sort_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles64);
+        return;
+    }
+    gather_fused_body<VEC>(ga, ((int)blockIdx.x - nsort) * (SORT_THREADS / 64) + (threadIdx.x >> 6));
 }
 
 // The index sort of a batch and its fused gather (K1) need nothing but the batch, and the sort keeps only F
@@ -681,14 +854,66 @@ int window_for(int d) {
 
 }  // namespace
 
+static int g_two_level = 1;
+
+namespace {
+struct TwoLevelShape { int it, tiles; };
+// Up to here the three launches cost what the single workgroup per field does (measured, MI355X, 39 fields:
+// 4096 entries 24 us either way; 8192: 34 against 48 us; 16384: 58 against 90 us).
+constexpr int TWO_LEVEL_ABOVE = 4096;
+// tiles of 1024*it entries, at most SORT_MAX_TILES of them
+bool two_level_shape(int n, int nsrc, TwoLevelShape* s) {
+    if (!g_two_level || nsrc != 1 || n <= TWO_LEVEL_ABOVE) return false;
+    s->it = n <= 4096 ? 1 : (n <= 8192 ? 2 : 4);
+    s->tiles = rs_cdiv(n, SORT_THREADS * s->it);
+    return s->tiles <= SORT_MAX_TILES;
+}
+inline unsigned long long* plan_tiles(int* plan, int F, int cap) {
+    return reinterpret_cast<unsigned long long*>(plan + (size_t)F * (6 * (size_t)cap + 2 + 4));
+}
+inline size_t sort_lds(int items) { return (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int); }
+
+// launches 2 and 3 of the two-level sort
+int launch_rank_tail(const SortArgs& a, const TwoLevelShape& sh, unsigned long long* tiles64, hipStream_t stream) {
+    unsigned long long* merged64 = tiles64 + (size_t)a.F * a.cap;
+    const size_t rsm = (size_t)sh.tiles * SORT_THREADS * sh.it * sizeof(unsigned);
+    const size_t tsm = (32 + SORT_THREADS) * sizeof(int);
+    const dim3 grid(a.F * sh.tiles), block(SORT_THREADS);
+#define RS_RANK_TAIL(IT)                                                                            \
+    do {                                                                                            \
+        static bool attr = false;                                                                   \
+        if (!attr && rsm > 48 * 1024) {                                                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(tile_rank_kernel<IT>),            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsm) != hipSuccess) { \
+                rs_set_error("sort merge: cannot reserve %zu bytes of LDS", rsm);                   \
+                return RS_ERR_LAUNCH;                                                               \
+            }                                                                                       \
+            attr = true;                                                                            \
+        }                                                                                           \
+        hipLaunchKernelGGL(tile_rank_kernel<IT>, grid, block, rsm, stream, a, sh.tiles, tiles64, merged64); \
+        hipLaunchKernelGGL(tile_tail_kernel<IT>, grid, block, tsm, stream, a, sh.tiles, merged64);  \
+    } while (0)
+    if (sh.it == 1) RS_RANK_TAIL(1);
+    else if (sh.it == 2) RS_RANK_TAIL(2);
+    else RS_RANK_TAIL(4);
+#undef RS_RANK_TAIL
+    return RS_OK;
+}
+}  // namespace
+
 extern "C" {
 
-// Bytes of int32 scratch per field-sort output set with capacity `cap` entries per field:
+// int32 elements of scratch per field-sort output set with capacity `cap` entries per field:
 //   sorted_src [F,cap] | entry_chunk [F,cap] | entry_seg [F,cap] | chunk_start [F,cap+1] | seg_row [F,cap] |
-//   seg_first_chunk [F,cap+1] | counts [F,4]
-size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (6 * (size_t)cap + 2 + 4); }
+//   seg_first_chunk [F,cap+1] | counts [F,4] | sorted tiles and merged list of the two-level sort 2 x [F,cap] x 64 bit
+size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (6 * (size_t)cap + 2 + 4) + 4 * (size_t)F * cap; }
 
 int rs_sort_max_entries(void) { return SORT_THREADS * 16; }
+
+// Lists of more than 4096 entries given as one sub-list per field are sorted in two levels (tiles, then a merge)
+// unless this is switched off; the plan is the same either way.  Returns the previous setting.
+int rs_sort_two_level(int on) { const int was = g_two_level; g_two_level = on ? 1 : 0; return was; }
+
 
 // Per-field stable radix sort + segmentation (see file header).  `plan` is int32 scratch of
 // rs_sort_plan_ints(F, cap) elements laid out as above.
@@ -708,10 +933,21 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.entry_seg = pv.entry_seg;
     a.chunk_start = pv.chunk_start; a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk;
     a.counts = pv.counts;
+    TwoLevelShape sh;
+    if (two_level_shape(max_entries, nsrc, &sh)) {
+        unsigned long long* tiles64 = plan_tiles(plan, F, cap);
+        const size_t tsm = sort_lds(sh.it);
+        if (sh.it == 1) hipLaunchKernelGGL(tile_sort_kernel<1>, dim3(F * sh.tiles), dim3(SORT_THREADS), tsm, stream, a, sh.tiles, tiles64);
+        else if (sh.it == 2) hipLaunchKernelGGL(tile_sort_kernel<2>, dim3(F * sh.tiles), dim3(SORT_THREADS), tsm, stream, a, sh.tiles, tiles64);
+        else hipLaunchKernelGGL(tile_sort_kernel<4>, dim3(F * sh.tiles), dim3(SORT_THREADS), tsm, stream, a, sh.tiles, tiles64);
+        const int rc = launch_rank_tail(a, sh, tiles64, stream);
+        if (rc != RS_OK) return rc;
+        RS_CHECK_LAUNCH("rs_sparse_bwd_sort");
+        return RS_OK;
+    }
     int items = 1;
     while (items * SORT_THREADS < max_entries) items <<= 1;
-    if (items < 4) items = 4;
-    const size_t smem = (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int);   // items, scan scratch, one count per thread
+    const size_t smem = sort_lds(items);   // items, scan scratch, one count per thread
 #define RS_SORT_LAUNCH(IT)                                                                          \
     do {                                                                                            \
         static bool attr = false;                                                                   \
@@ -725,7 +961,9 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
         }                                                                                           \
         hipLaunchKernelGGL(field_sort_kernel<IT>, dim3(F), dim3(SORT_THREADS), smem, stream, a);   \
     } while (0)
-    if (items == 4) RS_SORT_LAUNCH(4);
+    if (items == 1) RS_SORT_LAUNCH(1);
+    else if (items == 2) RS_SORT_LAUNCH(2);
+    else if (items == 4) RS_SORT_LAUNCH(4);
     else if (items == 8) RS_SORT_LAUNCH(8);
     else RS_SORT_LAUNCH(16);
 #undef RS_SORT_LAUNCH
@@ -759,10 +997,26 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
     else RS_CHECK_ARG(pick_layout(d, &VEC, &ga.G, &ga.C) == 0, "rs_sort_gather: unsupported embedding_dim %d", d);
     const int spw = 64 / (ga.G * ga.C);
     const int gblocks = rs_cdiv(rs_cdiv(B, spw), SORT_THREADS / 64);
+    TwoLevelShape sh;
+    if (two_level_shape(B, 1, &sh)) {
+        unsigned long long* tiles64 = plan_tiles(plan, F, cap);
+        const size_t tsm = sort_lds(sh.it);
+        const dim3 grid(F * sh.tiles + gblocks), block(SORT_THREADS);
+#define RS_TSG_LAUNCH(IT, V) hipLaunchKernelGGL((tile_sort_gather_kernel<IT, V>), grid, block, tsm, stream, a, sh.tiles, tiles64, ga)
+        if (VEC == 4) {
+            if (sh.it == 1) RS_TSG_LAUNCH(1, 4); else if (sh.it == 2) RS_TSG_LAUNCH(2, 4); else RS_TSG_LAUNCH(4, 4);
+        } else {
+            if (sh.it == 1) RS_TSG_LAUNCH(1, 1); else if (sh.it == 2) RS_TSG_LAUNCH(2, 1); else RS_TSG_LAUNCH(4, 1);
+        }
+#undef RS_TSG_LAUNCH
+        const int rc = launch_rank_tail(a, sh, tiles64, stream);
+        if (rc != RS_OK) return rc;
+        RS_CHECK_LAUNCH("rs_sort_gather");
+        return RS_OK;
+    }
     int items = 1;
     while (items * SORT_THREADS < B) items <<= 1;
-    if (items < 4) items = 4;
-    const size_t smem = (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int);
+    const size_t smem = sort_lds(items);
 #define RS_SG_LAUNCH(IT, V)                                                                         \
     do {                                                                                            \
         static bool attr = false;                                                                   \
@@ -777,9 +1031,11 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
         hipLaunchKernelGGL((sort_gather_kernel<IT, V>), dim3(F + gblocks), dim3(SORT_THREADS), smem, stream, a, ga); \
     } while (0)
     if (VEC == 4) {
-        if (items == 4) RS_SG_LAUNCH(4, 4); else if (items == 8) RS_SG_LAUNCH(8, 4); else RS_SG_LAUNCH(16, 4);
+        if (items == 1) RS_SG_LAUNCH(1, 4); else if (items == 2) RS_SG_LAUNCH(2, 4); else if (items == 4) RS_SG_LAUNCH(4, 4);
+        else if (items == 8) RS_SG_LAUNCH(8, 4); else RS_SG_LAUNCH(16, 4);
     } else {
-        if (items == 4) RS_SG_LAUNCH(4, 1); else if (items == 8) RS_SG_LAUNCH(8, 1); else RS_SG_LAUNCH(16, 1);
+        if (items == 1) RS_SG_LAUNCH(1, 1); else if (items == 2) RS_SG_LAUNCH(2, 1); else if (items == 4) RS_SG_LAUNCH(4, 1);
+        else if (items == 8) RS_SG_LAUNCH(8, 1); else RS_SG_LAUNCH(16, 1);
     }
 #undef RS_SG_LAUNCH
     RS_CHECK_LAUNCH("rs_sort_gather");

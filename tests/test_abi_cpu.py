@@ -35,7 +35,7 @@ def test_python_binding_covers_header():
 def test_host_side_queries():
     from recommendsystem_amd import _lib
     h = _lib.lib()
-    assert h.rs_sort_plan_ints(39, 4096) == 39 * (6 * 4096 + 6)
+    assert h.rs_sort_plan_ints(39, 4096) == 39 * (10 * 4096 + 6)
     assert h.rs_sort_max_entries() == 16384
     assert h.rs_sparse_window(16) == 16 and h.rs_sparse_window(1) == 64 and h.rs_sparse_window(20) == 8
     assert h.rs_gemm_workspace_bytes(100, 50, 4) == 4 * 100 * 50 * 4

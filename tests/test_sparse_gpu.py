@@ -80,6 +80,42 @@ def test_row_sets_and_row_grads(B, vocabs, d):
     assert torch.equal(grad, grad2)
 
 
+@pytest.mark.parametrize("B", [4097, 5000, 7000, 8192, 8193, 12345, 16384])
+def test_two_level_sort_writes_the_same_plan(B):
+    """Lists of more than 4096 entries are sorted as tiles and merged: the plan must equal the one-pass sort's
+    bit for bit (stable order, same chunks and segments), also beside the gather."""
+    from recommendsystem_amd import _lib, ops
+    vocabs = [3, 40, 5000, 1 << 20, 2_000_000_000]
+    idx, g = _case(B, vocabs, seed=B)
+    idx[1, : B // 2] = 7                      # one run longer than a tile
+    idx[2, ::3] = 0                           # padding spread over every tile
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    h = _lib.lib()
+    cap = min(B + 5, h.rs_sort_max_entries())
+    plans = []
+    was = h.rs_sort_two_level(1)
+    try:
+        for on in (0, 1):
+            h.rs_sort_two_level(on)
+            p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+            p.sort_columnar(idx.to(dev))
+            plans.append(p)
+        tiles_off = len(vocabs) * (6 * cap + 6)
+        assert torch.equal(plans[0].plan[:tiles_off], plans[1].plan[:tiles_off])
+        c = plans[1].counts().cpu()
+        assert (c[:, 0] == B).all() and int(c[2, 3]) == int((idx[2] == 0).sum())
+        # beside the gather
+        table = torch.randn(layout.total_rows, 16, device=dev)
+        p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+        out = p.sort_and_gather(idx.to(dev), table, None, torch.zeros(1, device=dev))
+        assert torch.equal(p.plan[:tiles_off], plans[0].plan[:tiles_off])
+        rows = (idx + torch.tensor(layout.row_offsets)[:, None]).t().to(dev)
+        assert torch.equal(out["emb"], table[rows])
+    finally:
+        h.rs_sort_two_level(was)
+
+
 def test_golden_table_grads():
     from recommendsystem_amd import ops
     g = load_golden("layers.npz")
