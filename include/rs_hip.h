@@ -216,6 +216,14 @@ int rs_sparse_window(int d);
 int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base, int pay_stride,
                        int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
                        const int64_t* row_offset, int* plan, rs_stream_t stream);
+/* rs_sparse_bwd_sort for sub-lists that are each ascending already (the owner side of the row-sharded exchange
+ * receives its keys that way): the same plan from a merge instead of a sort.  max_entries may reach
+ * rs_merge_max_entries() (beyond rs_sort_max_entries()); nsrc <= 16.  No counterpart in the reference, which has
+ * no multi-GPU path. */
+int rs_merge_max_entries(void);
+int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base, int pay_stride,
+                       int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
+                       const int64_t* row_offset, int* plan, rs_stream_t stream);
 /* rs_sparse_bwd_sort of a columnar batch idx [F, B] (sub_off[f] = f*B, sub_cnt[f] = B, pay_base[f] = f, stride F)
  * and rs_gather_lr_fm_fwd of the same batch in ONE launch: both need only the batch, and the sort occupies just F
  * workgroups, so the gather runs beside it (Layers.py:137-160 forward + the index bookkeeping of its backward). */

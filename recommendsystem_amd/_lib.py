@@ -37,6 +37,7 @@ _SIGS = {
     "rs_colsum_finish_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     # sparse.hip
     "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
+    "rs_sparse_bwd_merge_lists": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
     "rs_sort_gather": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
                        c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
@@ -112,6 +113,7 @@ _PLAIN = {
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_sort_max_entries": (I, []),
     "rs_sort_two_level": (I, [I]),
+    "rs_merge_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),
     "rs_act_bwd_num_partials": (I, [L]),

@@ -318,12 +318,70 @@ __device__ __forceinline__ void tile_rank_body(const SortArgs& a, int f, int q, 
     }
 }
 
+// ---- merge of nsrc ascending sub-lists per field (the owner side of the row-sharded exchange receives its keys
+// that way): no sort at all.  Workgroup (f, s) places the items of sub-list s: position in its own list plus, by
+// binary search, the items of every other list that go before it (equal keys: the earlier list first, as the
+// stable sort of the concatenated lists would have it).  The keys of all lists of the field sit in LDS, 4 bytes
+// each; tile_tail_kernel then segments the merged list.
+constexpr int MERGE_MAX_LISTS = 16;
+constexpr int MERGE_MAX_ENTRIES = 32768;
+
+template <bool UPPER>
+__device__ __forceinline__ int list_bound(const unsigned* list, int len, unsigned key) {
+    int lo = 0;
+    while (len > 0) {
+        const int half = len >> 1;
+        const unsigned k = list[lo + half];
+        if (UPPER ? k <= key : k < key) { lo += half + 1; len -= half + 1; }
+        else len = half;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void lists_rank_kernel(SortArgs a, unsigned long long* merged64) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lkeys[];             // [sum of the field's list lengths]
+    __shared__ int lbase[MERGE_MAX_LISTS + 1];
+    const int f = blockIdx.x / a.nsrc, s = blockIdx.x % a.nsrc;
+    const int t = threadIdx.x;
+    if (a.sub_cnt[s * a.F + f] == 0) return;                                     // uniform over the workgroup
+    if (t == 0) {
+        int acc = 0;
+        for (int o = 0; o < a.nsrc; ++o) { lbase[o] = acc; acc += a.sub_cnt[o * a.F + f]; }
+        lbase[a.nsrc] = acc;
+    }
+    __syncthreads();
+    const long long V = a.vocab[f];
+    for (int o = 0; o < a.nsrc; ++o) {
+        const int cnt = lbase[o + 1] - lbase[o], off = a.sub_off[o * a.F + f];
+        for (int j = t; j < cnt; j += SORT_THREADS) {
+            long long k = a.keys[off + j];
+            if (k < 0 || k >= V) k = 0;
+            lkeys[lbase[o] + j] = (unsigned)k;
+        }
+    }
+    __syncthreads();
+    const int cnt = lbase[s + 1] - lbase[s];
+    const int pb = a.pay_base[s * a.F + f];
+    unsigned long long* dst = merged64 + (long long)f * a.cap;
+    for (int j = t; j < cnt; j += SORT_THREADS) {
+        const unsigned key = lkeys[lbase[s] + j];
+        int rank = j;
+        for (int o = 0; o < a.nsrc; ++o) {
+            if (o == s) continue;
+            const int len = lbase[o + 1] - lbase[o];
+            rank += o < s ? list_bound<true>(lkeys + lbase[o], len, key) : list_bound<false>(lkeys + lbase[o], len, key);
+        }
+        dst[rank] = ((unsigned long long)key << 32) | (unsigned)(pb + j * a.pay_stride);
+    }
+}
+
 template <int IT>
 __device__ __forceinline__ void tile_tail_body(const SortArgs& a, int f, int q, int tiles, const unsigned long long* merged64) {
     extern __shared__ __attribute__((aligned(16))) int tail_scratch[];           // [32] + [1024]
     constexpr int TS = SORT_THREADS * IT;
     const int t = threadIdx.x;
-    const int n = a.sub_cnt[f];
+    int n = 0;
+    for (int s = 0; s < a.nsrc; ++s) n += a.sub_cnt[s * a.F + f];
     const bool last = q == tiles - 1;
     if (q * TS >= n && !last) return;                                            // uniform over the workgroup
     const unsigned long long* src = merged64 + (long long)f * a.cap;
@@ -968,6 +1026,50 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     else RS_SORT_LAUNCH(16);
 #undef RS_SORT_LAUNCH
     RS_CHECK_LAUNCH("rs_sparse_bwd_sort");
+    return RS_OK;
+}
+
+int rs_merge_max_entries(void) { return MERGE_MAX_ENTRIES; }
+
+// rs_sparse_bwd_sort for sub-lists that are each in ascending key order already: the same plan from a merge (two
+// launches of F*nsrc and F*ceil(max_entries/4096) workgroups) instead of a sort.  max_entries (the most entries any
+// field has over all its sub-lists) may reach rs_merge_max_entries(); nsrc <= 16.  Sub-lists that are not ascending
+// give an unspecified (in-bounds) plan.
+int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base,
+                              int pay_stride, int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,
+                              const int64_t* row_offset, int* plan, hipStream_t stream) {
+    RS_CHECK_ARG(keys && sub_off && sub_cnt && pay_base && vocab && row_offset && plan, "rs_sparse_bwd_merge_lists: null argument");
+    RS_CHECK_ARG(F > 0 && nsrc > 0 && nsrc <= MERGE_MAX_LISTS && cap > 0 && L > 0, "rs_sparse_bwd_merge_lists: bad sizes");
+    RS_CHECK_ARG(max_entries > 0 && max_entries <= cap, "rs_sparse_bwd_merge_lists: max_entries %d exceeds plan capacity %d", max_entries, cap);
+    RS_CHECK_ARG(max_entries <= MERGE_MAX_ENTRIES, "rs_sparse_bwd_merge_lists: %d entries per field exceed the limit %d",
+                 max_entries, MERGE_MAX_ENTRIES);
+    SortArgs a;
+    a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
+    a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
+    const PlanView pv = carve_plan(plan, F, cap);
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.entry_seg = pv.entry_seg;
+    a.chunk_start = pv.chunk_start; a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk;
+    a.counts = pv.counts;
+    unsigned long long* merged64 = plan_tiles(plan, F, cap) + (size_t)F * cap;
+    const size_t rsm = (size_t)max_entries * sizeof(unsigned);
+    static size_t reserved = 0;
+    if (rsm > 48 * 1024 && rsm > reserved) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lists_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                MERGE_MAX_ENTRIES * (int)sizeof(unsigned)) != hipSuccess) {
+            rs_set_error("rs_sparse_bwd_merge_lists: cannot reserve %d bytes of LDS", MERGE_MAX_ENTRIES * (int)sizeof(unsigned));
+            return RS_ERR_LAUNCH;
+        }
+        reserved = MERGE_MAX_ENTRIES * sizeof(unsigned);
+    }
+    hipLaunchKernelGGL(lists_rank_kernel, dim3(F * nsrc), dim3(SORT_THREADS), rsm, stream, a, merged64);
+    const int it = max_entries <= 4096 ? 1 : (max_entries <= 8192 ? 2 : 4);
+    const int tiles = rs_cdiv(max_entries, SORT_THREADS * it);
+    const size_t tsm = (32 + SORT_THREADS) * sizeof(int);
+    const dim3 grid(F * tiles), block(SORT_THREADS);
+    if (it == 1) hipLaunchKernelGGL(tile_tail_kernel<1>, grid, block, tsm, stream, a, tiles, merged64);
+    else if (it == 2) hipLaunchKernelGGL(tile_tail_kernel<2>, grid, block, tsm, stream, a, tiles, merged64);
+    else hipLaunchKernelGGL(tile_tail_kernel<4>, grid, block, tsm, stream, a, tiles, merged64);
+    RS_CHECK_LAUNCH("rs_sparse_bwd_merge_lists");
     return RS_OK;
 }
 

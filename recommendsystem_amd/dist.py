@@ -225,8 +225,9 @@ class HipShardKernels:
         """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows."""
         N = self.spec.N
         call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
-        self.plan_own.sort_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                 max_entries=N * self.cap_b)
+        # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
+        self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
+                                  max_entries=N * self.cap_b)
         self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
                              g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
 
@@ -267,8 +268,9 @@ class HipShardKernelsWide(HipShardKernels):
     def merge(self, recv_idx, grads, grads1, partials):
         N = self.spec.N
         call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
-        self.plan_own.sort_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                 max_entries=N * self.cap_b)
+        # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
+        self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
+                                  max_entries=N * self.cap_b)
         self.plan_own.reduce_wide(partials, grads.view(-1, self.d))
 
     def update(self, opt, hyper, scal, table, m, v, table1, m1, v1):

@@ -461,9 +461,8 @@ class SparsePlan:
         self.cap = int(cap)
         self.d = int(d)
         dev = device or layout.device
-        if cap > h.rs_sort_max_entries():
-            raise RSError(f"sparse backward: {cap} entries per field exceed the in-LDS sort limit "
-                          f"{h.rs_sort_max_entries()}")
+        if cap > h.rs_merge_max_entries():      # the sort itself takes rs_sort_max_entries(), merge_lists this many
+            raise RSError(f"sparse backward: {cap} entries per field exceed the plan limit {h.rs_merge_max_entries()}")
         # entries per wave window of the segmented reduction (chunks are cut at its multiples)
         self.CHUNK = h.rs_sparse_window(self.d)
         if self.CHUNK <= 0:
@@ -547,6 +546,15 @@ class SparsePlan:
         call("rs_sparse_bwd_sort", ptr(keys), ptr(sub_off), ptr(sub_cnt), ptr(pay_base), 1, nsrc, self.F, self.cap,
              int(max_entries), self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan),
              stream())
+
+    def merge_lists(self, keys, sub_off, sub_cnt, pay_base, nsrc: int, max_entries: int):
+        """sort_lists for sub-lists that are each ascending already: the same plan from a merge instead of a sort."""
+        _chk(keys, torch.int64, "keys")
+        for t, n in ((sub_off, "sub_off"), (sub_cnt, "sub_cnt"), (pay_base, "pay_base")):
+            _chk(t, torch.int32, n, (nsrc * self.F,))
+        call("rs_sparse_bwd_merge_lists", ptr(keys), ptr(sub_off), ptr(sub_cnt), ptr(pay_base), 1, nsrc, self.F,
+             self.cap, int(max_entries), self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t),
+             ptr(self.plan), stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
                Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None):

@@ -116,6 +116,50 @@ def test_two_level_sort_writes_the_same_plan(B):
         h.rs_sort_two_level(was)
 
 
+@pytest.mark.parametrize("nsrc,cap_b,vocabs", [
+    (2, 50, [7, 300]), (3, 700, [5, 90, 4000, 100000]), (8, 832, [40, 2000, 1 << 20]), (4, 3000, [3, 1 << 18]),
+    (16, 100, [1000]), (8, 3500, [50, 1 << 22]),
+])
+def test_merge_of_sorted_lists_equals_the_sort(nsrc, cap_b, vocabs):
+    """The owner side of the exchange gets N ascending, duplicate-free key lists per field: the merge must write
+    the plan the stable sort of the concatenated lists writes, bit for bit (ragged and empty lists included)."""
+    from recommendsystem_amd import ops
+    dev = "cuda:0"
+    F = len(vocabs)
+    g = torch.Generator().manual_seed(nsrc * 1000 + cap_b)
+    keys = torch.zeros(nsrc * F, cap_b + 1, dtype=torch.int64)
+    cnt = torch.zeros(nsrc * F, dtype=torch.int32)
+    for s_ in range(nsrc):
+        for f, v in enumerate(vocabs):
+            want = int(torch.randint(0, cap_b + 1, (1,), generator=g)) if (s_ + f) % 5 else 0     # some empty lists
+            ks = torch.unique(torch.randint(1, v, (want,), generator=g)) if want else torch.zeros(0, dtype=torch.int64)
+            keys[s_ * F + f, 1:1 + len(ks)] = ks
+            keys[s_ * F + f, 0] = len(ks)
+            cnt[s_ * F + f] = len(ks)
+    sf = torch.arange(nsrc * F, dtype=torch.int32)
+    sub_off, pay_base = (sf * (cap_b + 1) + 1).to(dev), (sf * cap_b).to(dev)
+    layout = ops.FieldLayout(vocabs, dev)
+    cap = nsrc * cap_b
+    pm = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    pm.merge_lists(keys.to(dev).view(-1), sub_off, cnt.to(dev), pay_base, nsrc, cap)
+    c = pm.counts().cpu()
+    for f in range(F):
+        assert int(c[f, 0]) == int(cnt.view(nsrc, F)[:, f].sum())
+    if cap <= 16384:
+        ps = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+        ps.sort_lists(keys.to(dev).view(-1), sub_off, cnt.to(dev), pay_base, nsrc, cap)
+        used = F * (6 * cap + 6)
+        assert torch.equal(ps.plan[:used], pm.plan[:used])
+    else:
+        # beyond the sort's capacity: distinct rows and their multiplicities against torch
+        seg_rows = pm.seg_rows().cpu()
+        for f in range(F):
+            allk = torch.cat([keys[s_ * F + f, 1:1 + int(cnt[s_ * F + f])] for s_ in range(nsrc)])
+            uniq = torch.unique(allk) + layout.row_offsets[f]
+            assert int(c[f, 2]) == len(uniq)
+            assert torch.equal(seg_rows[f, :len(uniq)].long(), uniq)
+
+
 def test_golden_table_grads():
     from recommendsystem_amd import ops
     g = load_golden("layers.npz")
