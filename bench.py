@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
+    p.add_argument("--tables", type=str, default="sharded", choices=["sharded", "replicated"],
+                   help="multi-GPU placement of the embedding tables: row-sharded with an all-to-all exchange, or a "
+                        "replica per rank with an all-gather of (row, gradient) pairs")
     p.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     p.add_argument("--overlap", type=int, default=0, help="run weight-gradient GEMMs and the index sort on side streams")
     p.add_argument("--uniform", type=int, default=0, help="uniform instead of Zipf(1.1) indices")
@@ -167,8 +170,9 @@ def main():
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
     fused_kind = getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep")
     if use_dist and fused_kind:
-        from recommendsystem_amd.dist import DistributedTrainer
-        eng = DistributedTrainer(model, mode=args.mode, use_graph={0: False, 1: True, 2: "full"}[args.dist_graph], stage_cpu=rehearse)
+        from recommendsystem_amd.dist import DistributedTrainer, ReplicatedTablesTrainer
+        cls = ReplicatedTablesTrainer if args.tables == "replicated" else DistributedTrainer
+        eng = cls(model, mode=args.mode, use_graph={0: False, 1: True, 2: "full"}[args.dist_graph], stage_cpu=rehearse)
     elif use_dist:
         from recommendsystem_amd.dist import DistributedSparseTrainer
         eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
@@ -340,7 +344,10 @@ def main():
                        "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
                        "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
-                       "parallelism": "single GPU" if world == 1 else f"dp{world} + row-sharded tables (RCCL all-to-all)"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"dp{world} + replicated tables (RCCL all-gather of (row, gradient) pairs)"
+                           if args.tables == "replicated" and fused_kind
+                           else f"dp{world} + row-sharded tables (RCCL all-to-all)")},
             "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_hbm_scatter": roofline_hbm_scatter,
             "cpu_baseline": cpu,
             "kernel_us_per_step": {k: round(v, 1) for k, v in per_step.items()},

@@ -124,6 +124,20 @@ class Comm:
         else:
             dist.broadcast(t, src, group=self.group)
 
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor):
+        """out [world, *inp.shape] (persistent) <- every rank's `inp`, in rank order."""
+        if self.recorder is not None:
+            return self.recorder.collective(lambda: self._all_gather_into(out, inp))
+        self._all_gather_into(out, inp)
+
+    def _all_gather_into(self, out, inp):
+        if self.stage_cpu and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather(list(o.unbind(0)), inp.cpu().contiguous(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=self.group)
+
     def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
         src = t.cpu() if (self.stage_cpu and t.is_cuda) else t
         outs = [torch.empty_like(src) for _ in range(self.world)]
@@ -505,6 +519,91 @@ class DistributedTrainer(FusedTrainer):
         for ex in self._ex.values():
             ex.check_overflow()
             ex.k.layout_own.check_indices()
+
+
+# -------------------------------------------------------------------------------------------------
+# the replicated-tables variant
+# -------------------------------------------------------------------------------------------------
+class ReplicatedTablesTrainer(FusedTrainer):
+    """Data-parallel step with every table replicated on every rank (for tables that fit one GPU).
+
+    Forward and backward are the single-GPU step on the rank's own batch.  Then, instead of an all-reduce of dense
+    table gradients, the (row, gradient) pairs of the DISTINCT rows each rank touched are all-gathered -- per field
+    an ascending key list and its summed gradients, rectangular buffers of the batch size -- merged per field
+    (`SparsePlan.merge_lists`: the N lists are sorted already) and summed in rank order, and every rank applies the
+    same touched-rows update to its replica, so the replicas stay bitwise identical without ever being exchanged.
+    The global gradient norm needs no collective of its own: every rank holds every table gradient after the merge.
+    Collectives per step: one all-reduce of the flat dense gradient, one all-gather each of keys, counts, row
+    gradients (and 1-dim gradients).  Limit: world * batch entries per field <= rs_merge_max_entries()."""
+
+    def __init__(self, model, use_graph: bool = False, group=None, stage_cpu: bool = False, **kw):
+        self.comm = Comm(group, stage_cpu=stage_cpu)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        kw.pop("mode", None)
+        super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
+        self._sort_can_fork = False
+        self._rp = {}
+        self.comm.broadcast(self.flat_w, 0)
+        for t in self.tables:
+            self.comm.broadcast(t["w"], 0)
+
+    def _replica_plan(self, B: int):
+        if B not in self._rp:
+            N, F, dev = self.world, self.F, self.device
+            rp = type("ReplicaPlan", (), {})()
+            rp.gplan = SparsePlan(self.layout, cap=N * B, d=self.d, with_lr=self.has_lr)
+            rp.partials = torch.zeros(rp.gplan.n_partials, dtype=torch.float32, device=dev)
+            rp.keys = torch.zeros((F, B), dtype=torch.int64, device=dev)
+            rp.keys_all = torch.zeros((N, F, B), dtype=torch.int64, device=dev)
+            rp.cnt = torch.zeros((F,), dtype=torch.int32, device=dev)
+            rp.cnt_all = torch.zeros((N, F), dtype=torch.int32, device=dev)
+            rp.g_all = torch.zeros((N, F, B, self.d), dtype=torch.float32, device=dev) if self.has_emb else None
+            rp.g1_all = torch.zeros((N, F, B), dtype=torch.float32, device=dev) if self.has_lr else None
+            sf = torch.arange(N * F, dtype=torch.int32, device=dev)
+            rp.sub_off = sf * B
+            rp.pay_base = sf * B
+            rp.row_off = self.layout.row_offset_t.view(F, 1)
+            self._rp[B] = rp
+        return self._rp[B]
+
+    def _grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None, splitk=None):
+        B = idx.shape[1]
+        if plan.cap != B:
+            raise RSError("replicated tables: the plan capacity must equal the batch size")
+        FusedTrainer._embed_backward(self, plan, idx, gout, dz, ctx, sorted_already)     # one gradient per distinct row
+        rp, c = self._replica_plan(B), self.comm
+        torch.sub(plan.seg_rows().long(), rp.row_off, out=rp.keys)                     # stacked row -> key inside its field
+        rp.cnt.copy_(plan.counts()[:, 2])
+        c.all_gather_into(rp.keys_all, rp.keys)
+        c.all_gather_into(rp.cnt_all, rp.cnt)
+        if self.has_emb:
+            c.all_gather_into(rp.g_all, plan.rowgrad)
+        if self.has_lr:
+            c.all_gather_into(rp.g1_all, plan.rowgrad1)
+        N = self.world
+        rp.gplan.merge_lists(rp.keys_all.view(-1), rp.sub_off, rp.cnt_all.view(-1), rp.pay_base, nsrc=N, max_entries=N * B)
+        rp.gplan.reduce(rp.partials, gout=rp.g_all.view(-1, self.d) if self.has_emb else None,
+                        g1src=rp.g1_all.view(-1) if self.has_lr else None, Fdiv=1)
+        P = plan.partials
+        P[:plan.n_partials].zero_()
+        ops.colsum(rp.partials.view(-1, 1), out=P[0:1])
+
+    def _reduce_dense_grads(self):
+        self.comm.all_reduce(self.flat_g)
+
+    def _embed_update(self, plan, with_dense=False):
+        FusedTrainer._embed_update(self, self._rp[plan.cap].gplan, with_dense=with_dense)
+
+    _capture = DistributedTrainer._capture
+
+    def sync_to_model(self):
+        """Nothing to gather: the model's tables are this rank's replica."""
+
+    def check(self):
+        self.layout.check_indices()
 
 
 # -------------------------------------------------------------------------------------------------

@@ -168,14 +168,16 @@ def build_gpu_model(kind, optimizer, batch):
     return m
 
 
-def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False):
-    from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer
+def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False, replicated=False):
+    from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer, ReplicatedTablesTrainer
     rank, N = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     vocab, batch, steps = GPU_VOCAB, GPU_BATCH, GPU_STEPS
     m = build_gpu_model(kind, optimizer, batch)
     if generic:
         eng = DistributedSparseTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
+    elif replicated:
+        eng = ReplicatedTablesTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
     else:
         eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
     losses = []
@@ -200,6 +202,7 @@ if __name__ == "__main__":
             run_cpu(outdir)
         else:
             extra = sys.argv[5] if len(sys.argv) > 5 else ""
-            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=extra == "graph", generic=extra == "generic")
+            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=extra in ("graph", "replicated_graph"),
+                    generic=extra == "generic", replicated=extra.startswith("replicated"))
     finally:
         dist.destroy_process_group()

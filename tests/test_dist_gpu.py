@@ -65,3 +65,20 @@ def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tm
         if not v.dtype.is_floating_point:
             continue
         torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("kind,optimizer,extra", [("deepfm", "Adam", "replicated"), ("fm", "SGD", "replicated"),
+                                                  ("lr", "AdamW", "replicated"), ("deepfm", "Adagrad", "replicated_graph")])
+def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
+    """ReplicatedTablesTrainer: every rank keeps whole tables and merges the all-gathered (row, gradient) pairs."""
+    world = 2
+    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer, extra], timeout=200)
+    assert codes == [0] * world, "\n".join(outs)
+    got = np.load(tmp_path / "state.npz")
+    m, losses = single_gpu_reference(kind, optimizer, world)
+    lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
+    np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
