@@ -167,7 +167,8 @@ def ptr(t):
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream without building a torch.cuda.Stream object (eager steps ask ~30 times)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_cuda(*tensors):
@@ -180,7 +181,15 @@ def require_cuda(*tensors):
 n_calls = 0      # entry-point calls so far (lets a graph recorder tell an empty segment from one with launches)
 
 
+_fn_cache = {}
+
+
 def call(name: str, *args):
     global n_calls
     n_calls += 1
-    check(getattr(lib(), name)(*args), name)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)

@@ -151,6 +151,9 @@ OPT_CODES = {"SGD": 0, "Adam": 1, "AdamW": 2, "Adagrad": 3}
 # ---------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------
+_gemm_plans = {}       # (M, N, K) -> (tile, splitk) of rs_gemm_plan
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
          mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None,
          defer_reduce=None) -> torch.Tensor:
@@ -182,13 +185,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
         return out
     h = _lib.lib()
     if splitk <= 0 or tile < 0:
-        import ctypes as C
-        sk = C.c_int(1)
-        t = h.rs_gemm_plan(M, N, K, 256, C.byref(sk))
+        plan = _gemm_plans.get((M, N, K))
+        if plan is None:
+            import ctypes as C
+            sk = C.c_int(1)
+            t = h.rs_gemm_plan(M, N, K, 256, C.byref(sk))
+            plan = _gemm_plans[(M, N, K)] = (t, sk.value)
         if tile < 0:
-            tile = t
+            tile = plan[0]
         if splitk <= 0:
-            splitk = sk.value
+            splitk = plan[1]
     ws = ws or default_workspace(a.device)
     if (defer_reduce is not None and splitk > 1 and splitk * 32 <= K and bias is None and act == 0 and mulsrc is None
             and colsum_part is None and out.is_contiguous()):
