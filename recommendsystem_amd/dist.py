@@ -524,6 +524,68 @@ class DistributedTrainer(FusedTrainer):
 # -------------------------------------------------------------------------------------------------
 # the replicated-tables variant
 # -------------------------------------------------------------------------------------------------
+class HipReplicaKernels:
+    """Device side of the replicated-tables merge on librs_hip.so (tests/test_dist_cpu.py substitutes a torch-CPU
+    stand-in with the same methods)."""
+
+    def __init__(self, layout: FieldLayout, N: int, B: int, d: int, with_emb: bool, with_lr: bool, device):
+        self.N, self.B, self.d, self.F = N, B, d, layout.num_fields
+        self.with_emb, self.with_lr = with_emb, with_lr
+        self.gplan = SparsePlan(layout, cap=N * B, d=d, with_lr=with_lr)
+        sf = torch.arange(N * self.F, dtype=torch.int32, device=device)
+        self.sub_off = sf * B
+        self.pay_base = sf * B
+        self.row_off = layout.row_offset_t.view(self.F, 1)
+
+    @property
+    def n_partials(self):
+        return self.gplan.n_partials
+
+    def keys_of(self, seg_rows, out):
+        """stacked-table rows [F, B] (int32) -> keys inside their field (int64)."""
+        torch.sub(seg_rows.long(), self.row_off, out=out)
+
+    def merge(self, keys_all, cnt_all, g_all, g1_all, partials):
+        """N ascending key lists per field + their gradients -> one gradient per distinct row (gplan.rowgrad /
+        rowgrad1, rows in gplan.seg_rows()), ||g||^2 partials."""
+        N, B = self.N, self.B
+        self.gplan.merge_lists(keys_all.view(-1), self.sub_off, cnt_all.view(-1), self.pay_base, nsrc=N, max_entries=N * B)
+        self.gplan.reduce(partials, gout=g_all.view(-1, self.d) if g_all is not None else None,
+                          g1src=g1_all.view(-1) if g1_all is not None else None, Fdiv=1)
+
+
+class ReplicaExchange:
+    """All-gather of every rank's distinct (row, gradient) pairs -- per field an ascending key list of at most B
+    entries with its summed gradients, rectangular buffers -- and their merge in rank order."""
+
+    def __init__(self, kernels, comm: Comm, F: int, B: int, d: int, with_emb: bool, with_lr: bool, device):
+        self.k, self.comm = kernels, comm
+        N = comm.world
+        z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=device)
+        self.keys = z((F, B), torch.int64)
+        self.keys_all = z((N, F, B), torch.int64)
+        self.cnt = z((F,), torch.int32)
+        self.cnt_all = z((N, F), torch.int32)
+        self.g_all = z((N, F, B, d)) if with_emb else None
+        self.g1_all = z((N, F, B)) if with_lr else None
+        self.partials = z((kernels.n_partials,))
+
+    def merge(self, seg_rows, n_seg, rowgrad, rowgrad1):
+        """seg_rows [F, B] int32 stacked rows (ascending per field, n_seg[f] valid), rowgrad [F, B, d] / rowgrad1
+        [F, B]: this rank's distinct rows and gradients.  Leaves the merged result in the kernels object."""
+        c = self.comm
+        self.k.keys_of(seg_rows, self.keys)
+        self.cnt.copy_(n_seg)
+        c.all_gather_into(self.keys_all, self.keys)
+        c.all_gather_into(self.cnt_all, self.cnt)
+        if self.g_all is not None:
+            c.all_gather_into(self.g_all, rowgrad)
+        if self.g1_all is not None:
+            c.all_gather_into(self.g1_all, rowgrad1)
+        self.k.merge(self.keys_all, self.cnt_all, self.g_all, self.g1_all, self.partials)
+
+
+
 class ReplicatedTablesTrainer(FusedTrainer):
     """Data-parallel step with every table replicated on every rank (for tables that fit one GPU).
 
@@ -547,23 +609,10 @@ class ReplicatedTablesTrainer(FusedTrainer):
         for t in self.tables:
             self.comm.broadcast(t["w"], 0)
 
-    def _replica_plan(self, B: int):
+    def _replica(self, B: int) -> "ReplicaExchange":
         if B not in self._rp:
-            N, F, dev = self.world, self.F, self.device
-            rp = type("ReplicaPlan", (), {})()
-            rp.gplan = SparsePlan(self.layout, cap=N * B, d=self.d, with_lr=self.has_lr)
-            rp.partials = torch.zeros(rp.gplan.n_partials, dtype=torch.float32, device=dev)
-            rp.keys = torch.zeros((F, B), dtype=torch.int64, device=dev)
-            rp.keys_all = torch.zeros((N, F, B), dtype=torch.int64, device=dev)
-            rp.cnt = torch.zeros((F,), dtype=torch.int32, device=dev)
-            rp.cnt_all = torch.zeros((N, F), dtype=torch.int32, device=dev)
-            rp.g_all = torch.zeros((N, F, B, self.d), dtype=torch.float32, device=dev) if self.has_emb else None
-            rp.g1_all = torch.zeros((N, F, B), dtype=torch.float32, device=dev) if self.has_lr else None
-            sf = torch.arange(N * F, dtype=torch.int32, device=dev)
-            rp.sub_off = sf * B
-            rp.pay_base = sf * B
-            rp.row_off = self.layout.row_offset_t.view(F, 1)
-            self._rp[B] = rp
+            k = HipReplicaKernels(self.layout, self.world, B, self.d, self.has_emb, self.has_lr, self.device)
+            self._rp[B] = ReplicaExchange(k, self.comm, self.F, B, self.d, self.has_emb, self.has_lr, self.device)
         return self._rp[B]
 
     def _grad_scale(self) -> float:
@@ -574,28 +623,18 @@ class ReplicatedTablesTrainer(FusedTrainer):
         if plan.cap != B:
             raise RSError("replicated tables: the plan capacity must equal the batch size")
         FusedTrainer._embed_backward(self, plan, idx, gout, dz, ctx, sorted_already)     # one gradient per distinct row
-        rp, c = self._replica_plan(B), self.comm
-        torch.sub(plan.seg_rows().long(), rp.row_off, out=rp.keys)                     # stacked row -> key inside its field
-        rp.cnt.copy_(plan.counts()[:, 2])
-        c.all_gather_into(rp.keys_all, rp.keys)
-        c.all_gather_into(rp.cnt_all, rp.cnt)
-        if self.has_emb:
-            c.all_gather_into(rp.g_all, plan.rowgrad)
-        if self.has_lr:
-            c.all_gather_into(rp.g1_all, plan.rowgrad1)
-        N = self.world
-        rp.gplan.merge_lists(rp.keys_all.view(-1), rp.sub_off, rp.cnt_all.view(-1), rp.pay_base, nsrc=N, max_entries=N * B)
-        rp.gplan.reduce(rp.partials, gout=rp.g_all.view(-1, self.d) if self.has_emb else None,
-                        g1src=rp.g1_all.view(-1) if self.has_lr else None, Fdiv=1)
+        rx = self._replica(B)
+        rx.merge(plan.seg_rows(), plan.counts()[:, 2], plan.rowgrad if self.has_emb else None,
+                 plan.rowgrad1 if self.has_lr else None)
         P = plan.partials
         P[:plan.n_partials].zero_()
-        ops.colsum(rp.partials.view(-1, 1), out=P[0:1])
+        ops.colsum(rx.partials.view(-1, 1), out=P[0:1])
 
     def _reduce_dense_grads(self):
         self.comm.all_reduce(self.flat_g)
 
     def _embed_update(self, plan, with_dense=False):
-        FusedTrainer._embed_update(self, self._rp[plan.cap].gplan, with_dense=with_dense)
+        FusedTrainer._embed_update(self, self._rp[plan.cap].k.gplan, with_dense=with_dense)
 
     _capture = DistributedTrainer._capture
 

@@ -127,3 +127,40 @@ class TorchShardKernels:
     @property
     def n_own_partials(self):
         return 4
+
+
+class TorchReplicaKernels:
+    """Torch-CPU stand-in for recommendsystem_amd.dist.HipReplicaKernels: the same methods on the same buffer layouts
+    (keys_all [N, F, B], cnt_all [N, F], g_all [N, F, B, d], g1_all [N, F, B]); the merged gradients are left as dense
+    tables `grad` / `grad1` over the stacked rows, lists added in rank order."""
+
+    def __init__(self, vocab, N, B, d):
+        self.vocab, self.N, self.B, self.d, self.F = list(vocab), N, B, d, len(vocab)
+        self.off = [0]
+        for v in self.vocab[:-1]:
+            self.off.append(self.off[-1] + v)
+        self.total = sum(self.vocab)
+        self.grad = self.grad1 = None
+
+    @property
+    def n_partials(self):
+        return 4
+
+    def keys_of(self, seg_rows, out):
+        out.copy_(seg_rows.long() - torch.tensor(self.off).view(self.F, 1))
+
+    def merge(self, keys_all, cnt_all, g_all, g1_all, partials):
+        self.grad = torch.zeros(self.total, self.d)
+        self.grad1 = torch.zeros(self.total)
+        for s in range(self.N):
+            for f in range(self.F):
+                n = int(cnt_all[s, f])
+                keys = keys_all[s, f, :n]
+                assert bool((keys[1:] > keys[:-1]).all()), "lists must be ascending and duplicate-free"
+                rows = keys + self.off[f]
+                if g_all is not None:
+                    self.grad.index_add_(0, rows, g_all[s, f, :n])
+                if g1_all is not None:
+                    self.grad1.index_add_(0, rows, g1_all[s, f, :n])
+        partials.zero_()
+        partials[0] = (self.grad ** 2).sum() + (self.grad1 ** 2).sum()

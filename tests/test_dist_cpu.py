@@ -37,3 +37,12 @@ def test_exchange_protocol_gloo(world, tmp_path):
     assert codes == [0] * world, "\n".join(outs)
     for r in range(world):
         assert os.path.exists(tmp_path / f"ok{r}")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replica_exchange_gloo(world, tmp_path):
+    """Replicated tables: the all-gathered (row, gradient) lists merge to the union batch's gradient on every rank."""
+    codes, outs = run_ranks(world, ["cpu_replica", str(tmp_path)])
+    assert codes == [0] * world, "\n".join(outs)
+    for r in range(world):
+        assert os.path.exists(tmp_path / f"ok{r}")
