@@ -331,8 +331,8 @@ def main():
     if rank == 0:
         total = args.batch * world * args.steps
         out = {
-            "metric": "train samples/sec (node) DeepFM Criteo_x1 bs=4096" if args.model == "deepfm"
-                      else f"train samples/sec (node) {args.model}",
+            "metric": "train samples/sec (node) DeepFM Criteo_x1 bs=4096" if args.model == "deepfm" and args.batch == 4096
+                      else f"train samples/sec (node) {args.model} bs={args.batch}",
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -12,4 +12,9 @@ run --model fm --cpu-baseline 0
 for m in ffm pnn_inner dcn nfm afm; do
   run --model $m --steps 20 --warmup 5 --cpu-baseline 0
 done
+# the batch size the reference's PNN / DCN configuration names (tiled index sort above 4096 entries per field)
+for m in dcn pnn_inner; do
+  run --model $m --batch 16384 --steps 10 --warmup 3 --cpu-baseline 0
+done
+run --batch 16384 --steps 20 --warmup 5 --cpu-baseline 0
 run --model pnn --steps 5 --warmup 2 --cpu-baseline 0 --distinct-batches 2
