@@ -128,7 +128,10 @@ int rs_bce_head(const float* z0, const float* z1, const float* z2, const float* 
  * h = act(X.w + b), logit = z0 + z1 + h (z0, z1 nullable), loss, dz, dzh = dz*act'(h) and their sums in one launch;
  * and its backward dX = dzh w^T * act'_prev(X) plus part [rs_head_bwd_rows(B), 2K]: partial sums of
  * [dW = X^T dzh | dbp = column sums of dX], to be added over rows by rs_colsum_finish_multi.
- * ws: rs_head_workspace_floats(B, K) floats; sem: one int, zero before the first call, left zero. */
+ * ws: rs_head_workspace_floats(B, K) floats; sem: one int, zero before the first call, left zero.
+ * sem == NULL: the three batch sums are left to the caller: ws[4g + {0,1,2}], g < ceil(B/16), holds loss/B, sum dz
+ * and sum dzh of 16 rows each, to be added over g (rs_colsum_finish_multi, ld = 4); loss_out, sum_dz_out and
+ * sum_dzh_out are then not written. */
 size_t rs_head_workspace_floats(int B, int K);
 int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
                     const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,

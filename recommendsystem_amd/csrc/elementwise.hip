@@ -154,12 +154,22 @@ __global__ __launch_bounds__(256) void head_fwd_bce_kernel(const float* __restri
             if (dzh_out) dzh_out[m] = dzh;
         }
         l = rs_wave_sum(l); dz = rs_wave_sum(dz); dzh = rs_wave_sum(dzh);
+        if (sem == nullptr) {
+            // deferred sums: the caller adds the columns of part (loss already scaled by 1/B) in a later launch
+            if (lane == 0) {
+                part[blockIdx.x * 4 + 0] = l * (1.f / (float)B);
+                part[blockIdx.x * 4 + 1] = dz;
+                part[blockIdx.x * 4 + 2] = dzh;
+            }
+            return;
+        }
         if (lane == 0) {
             rs_st_agent(part + blockIdx.x * 4 + 0, l);
             rs_st_agent(part + blockIdx.x * 4 + 1, dz);
             rs_st_agent(part + blockIdx.x * 4 + 2, dzh);
         }
     }
+    if (sem == nullptr) return;                          // uniform over the launch
     if (!rs_last_arrival(sem, gridDim.x, &s_flag)) return;
     if (wv == 0) {
         float l = 0.f, dz = 0.f, dzh = 0.f;
@@ -482,11 +492,14 @@ size_t rs_head_workspace_floats(int M, int K) {
 
 // 1-wide last layer + sigmoid/BCE head in one launch (see head_fwd_bce_kernel).  z0, z1: the other logit
 // parts (nullable; z1 needs z0).  sem: one zeroed int (left zero).  ws: rs_head_workspace_floats(B, K).
+// sem == NULL: the three batch sums are left to the caller -- ws[g*4 + {0,1,2}], g < ceil(B/16), holds per 16 rows the
+// loss / B, sum dz and sum dzh, to be added over g (rs_colsum_finish_multi with ld = 4); loss_out, sum_dz_out and
+// sum_dzh_out are not written.
 int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
                     const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
                     float* loss_out, float* dz_out, float* sum_dz_out, float* dzh_out, float* sum_dzh_out, float* ws,
                     int* sem, hipStream_t stream) {
-    RS_CHECK_ARG(B > 0 && K > 0 && X && w && ws && sem, "rs_head_fwd_bce: bad arguments");
+    RS_CHECK_ARG(B > 0 && K > 0 && X && w && ws, "rs_head_fwd_bce: bad arguments");
     RS_CHECK_ARG((K & 3) == 0 && ((((uintptr_t)X | (uintptr_t)w) & 15) == 0), "rs_head_fwd_bce: K %% 4 and 16-byte alignment");
     RS_CHECK_ARG((labels_f32 != nullptr) != (labels_i64 != nullptr), "rs_head_fwd_bce: pass exactly one label array");
     RS_CHECK_ARG(z0 || !z1, "rs_head_fwd_bce: z1 without z0");

@@ -340,12 +340,14 @@ class FusedTrainer:
         sort_early = self._fuse_small and not fork_sort
         parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
         lastb = self.blocks[-1] if self.blocks else None
+        # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
+        csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None
         if head_fast:
             # the 1-wide last block, the loss and dL/dlogit in one launch
             head = ops.head_fwd_bce(ctx["head_in"], lastb.fc.weight.data.view(-1), lastb.fc.bias.data, lastb._act, parts,
                                     labels, grad_scale=self._grad_scale(),
                                     sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None,
-                                    sum_dzh_out=self.gviews[id(lastb.fc.bias)])
+                                    sum_dzh_out=self.gviews[id(lastb.fc.bias)], defer=csp)
             parts = parts + [head["h"]]
         else:
             head = ops.bce_head(parts, labels, want_dz=True, grad_scale=self._grad_scale(),
@@ -374,7 +376,6 @@ class FusedTrainer:
             # weight gradients are read by nobody before the gradient norm: their split-K slabs are reduced together
             skp = ops.SplitKParts(ops.default_workspace(self.device)) if not overlap else None
             db_done = False              # the bias gradient of the block about to be visited is already on its way
-            csp = ops.ColsumParts(ops.default_workspace(self.device))    # partial column sums -> one finishing launch
             if head_fast:
                 _, xin, _ = cs[top]
                 prev = self.blocks[top - 1] if top > 0 else None

@@ -379,9 +379,10 @@ def bce_head(parts, labels: torch.Tensor, want_logit=False, want_prob=False, wan
 
 
 def head_fwd_bce(x: torch.Tensor, w: torch.Tensor, bias, act: int, parts, labels: torch.Tensor, grad_scale=1.0,
-                 sum_dz_out=None, sum_dzh_out=None, ws: Optional[Workspace] = None):
+                 sum_dz_out=None, sum_dzh_out=None, ws: Optional[Workspace] = None, defer: "ColsumParts" = None):
     """1-wide last layer + loss head in one launch: h = act(x.w + b); logit = sum(parts) + h.
-    Returns dict(loss [1], dz [B], dzh [B], h [B])."""
+    Returns dict(loss [1], dz [B], dzh [B], h [B]).  defer: a ColsumParts collector; the loss and the two batch sums
+    are then only valid after its finish() (the kernel leaves per-workgroup partial sums and skips its own tail)."""
     _chk(x, torch.float32, "x")
     B, K = x.shape
     _chk(w, torch.float32, "w")
@@ -404,12 +405,19 @@ def head_fwd_bce(x: torch.Tensor, w: torch.Tensor, bias, act: int, parts, labels
     dev = x.device
     ws = ws or default_workspace(dev)
     wbuf = ws.get("head_ws", _lib.lib().rs_head_workspace_floats(B, K))
-    sem = ws.get("head_sem", 1, dtype=torch.int32, zero=True)
+    sem = ws.get("head_sem", 1, dtype=torch.int32, zero=True) if defer is None else None
     out = {k: torch.empty(B, dtype=torch.float32, device=dev) for k in ("dz", "dzh", "h")}
     out["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
     call("rs_head_fwd_bce", ptr(x), B, K, ptr(w), ptr(bias), int(act), ptr(parts[0]), ptr(parts[1]), ptr(lf), ptr(li),
          float(grad_scale), ptr(out["h"]), ptr(out["loss"]), ptr(out["dz"]), ptr(sum_dz_out), ptr(out["dzh"]),
          ptr(sum_dzh_out), ptr(wbuf), ptr(sem), stream())
+    if defer is not None:
+        rows = (B + 15) // 16
+        defer.add(wbuf, rows, 1, 4, dest=out["loss"], offset=0)
+        if sum_dz_out is not None:
+            defer.add(wbuf, rows, 1, 4, dest=sum_dz_out, offset=1)
+        if sum_dzh_out is not None:
+            defer.add(wbuf, rows, 1, 4, dest=sum_dzh_out, offset=2)
     return out
 
 

@@ -291,6 +291,39 @@ def test_clip_coef_and_dense_update():
     torch.testing.assert_close(w.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,K", [(4096, 256), (37, 64), (1000, 512)])
+def test_fused_head_both_forms_match_torch(B, K):
+    """1-wide last block + BCE head in one launch: the form that finishes its batch sums itself and the form that
+    leaves them to the shared column-sum launch, against torch autograd (fp32, 1e-5)."""
+    from recommendsystem_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(B + K)
+    x = torch.randn(B, K, generator=g)
+    w = (torch.randn(K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(1, generator=g).requires_grad_(True)
+    z0, z1 = torch.randn(B, generator=g), torch.randn(B, generator=g)
+    y = (torch.rand(B, generator=g) < 0.3).float()
+    h = torch.relu(x @ w + b)
+    h.retain_grad()                 # dL/dh, the gradient behind the activation
+    z = (z0 + z1) + h
+    loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(z), y)
+    loss.backward()
+    dz_ref = (torch.sigmoid(z) - y).detach() / B
+    for deferred in (False, True):
+        csp = ops.ColsumParts(ops.default_workspace(dev)) if deferred else None
+        s_dz, s_dzh = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        out = ops.head_fwd_bce(x.to(dev), w.detach().to(dev), b.detach().to(dev), 1, [z0.to(dev), z1.to(dev)], y.to(dev),
+                               sum_dz_out=s_dz, sum_dzh_out=s_dzh, defer=csp)
+        if deferred:
+            csp.finish()
+        torch.testing.assert_close(out["loss"].cpu()[0], loss.detach(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(out["h"].cpu(), h.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out["dz"].cpu(), dz_ref, rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(out["dzh"].cpu(), h.grad * (h.detach() > 0), rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(s_dz.cpu()[0], dz_ref.sum(), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(s_dzh.cpu()[0], b.grad[0], rtol=1e-4, atol=1e-7)
+
+
 def test_bce_head_matches_torch():
     from recommendsystem_amd import ops
     g = torch.Generator().manual_seed(4)
