@@ -137,6 +137,12 @@ int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* b
                     const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
                     float* loss_out, float* dz_out, float* sum_dz_out, float* dzh_out, float* sum_dzh_out, float* ws,
                     int* sem, rs_stream_t stream);
+/* rs_head_fwd_bce in its sem == NULL form and rs_head_bwd in one launch (X is read once): h, dz, dzh, the batch-sum
+ * partials in ws, dX [B, K] and part [rs_head_bwd_rows(B), 2K].  K % 4 == 0, K <= 1024.  (DeepFM.py:35 forward and
+ * backward of the 1-wide block + BaseModel.py:145.) */
+int rs_head_fwd_bwd(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
+                    const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
+                    float* dz_out, float* dzh_out, float* ws, int mul_act, float* dX, float* part, rs_stream_t stream);
 int rs_head_bwd_rows(int B);
 int rs_head_bwd(const float* dzh, const float* w, const float* X, int mul_act, int B, int K, float* dX, float* part,
                 rs_stream_t stream);

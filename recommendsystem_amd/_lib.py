@@ -63,6 +63,8 @@ _SIGS = {
     "rs_rowdot_bwd_dx": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_head_fwd_bce": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_f32p, c_f32p, c_i64p, F, c_f32p, c_f32p, c_f32p,
                         c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream],
+    "rs_head_fwd_bwd": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_f32p, c_f32p, c_i64p, F, c_f32p, c_f32p, c_f32p,
+                        c_f32p, I, c_f32p, c_f32p, c_stream],
     "rs_head_bwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_act_fwd": [c_f32p, c_f32p, L, I, c_f32p, c_stream],
     "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],

@@ -222,6 +222,112 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
+// head_fwd_bce_kernel and head_bwd_kernel in one launch: the 16 rows a workgroup has just used for the dot products
+// are still in its registers when their dzh is known, so dX, and the workgroup's partial rows of dW and dbp, come
+// out without reading X again.  Batch sums: left as partials (part4, see head_fwd_bce_kernel with sem == nullptr).
+// KI = ceil(K / 256) float4 columns per lane, K <= 1024.
+template <int KI>
+__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const float* __restrict__ X, int B, int K,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int act, const float* __restrict__ z0,
+                                                           const float* __restrict__ z1, const float* __restrict__ yf,
+                                                           const int64_t* __restrict__ yi, float grad_scale,
+                                                           float* __restrict__ h_out, float* __restrict__ dz_out,
+                                                           float* __restrict__ dzh_out, float* __restrict__ part4,
+                                                           int mul_act, float* __restrict__ dX,
+                                                           float* __restrict__ prow_all /*[grid,2,K]*/) {
+    extern __shared__ float wred[];                     // [4 waves][2K]
+    __shared__ float hrow[HEAD_ROWS], sdzh[HEAD_ROWS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * HEAD_ROWS;
+    const float b0 = bias ? bias[0] : 0.f;
+    float4 a[KI][4], c[KI];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int k = lane * 4 + it * 256;
+        const bool in = k < K;
+        c[it] = in ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = r0 + wv * 4 + i;
+            a[it][i] = (in && m < B) ? *reinterpret_cast<const float4*>(X + (long long)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i] = fmaf(a[it][i].x, c[it].x, s[i]); s[i] = fmaf(a[it][i].y, c[it].y, s[i]);
+            s[i] = fmaf(a[it][i].z, c[it].z, s[i]); s[i] = fmaf(a[it][i].w, c[it].w, s[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = rs_wave_sum(s[i]);
+        if (lane == 0) hrow[wv * 4 + i] = rs_act(act, t + b0, 0.f);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int m = r0 + lane;
+        float l = 0.f, dz = 0.f, dzh = 0.f;
+        if (lane < HEAD_ROWS && m < B) {
+            const float h = hrow[lane];
+            float z = h;
+            if (z0 && z1) z = (z0[m] + z1[m]) + h;
+            else if (z0) z = z0[m] + h;
+            const float y = yf ? yf[m] : (float)yi[m];
+            const float p = 1.f / (1.f + expf(-z));
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+            l = -(y * lp + (1.f - y) * l1p);
+            const float gp = (p - y) / fmaxf((1.f - p) * p, 1e-12f) * (1.f / (float)B) * grad_scale;
+            dz = gp * ((1.f - p) * p);
+            dzh = dz * rs_act_grad(act, h, h, 0.f);
+            if (h_out) h_out[m] = h;
+            if (dz_out) dz_out[m] = dz;
+            if (dzh_out) dzh_out[m] = dzh;
+        }
+        if (lane < HEAD_ROWS) sdzh[lane] = dzh;
+        l = rs_wave_sum(l); dz = rs_wave_sum(dz); dzh = rs_wave_sum(dzh);
+        if (lane == 0) {
+            part4[blockIdx.x * 4 + 0] = l * (1.f / (float)B);
+            part4[blockIdx.x * 4 + 1] = dz;
+            part4[blockIdx.x * 4 + 2] = dzh;
+        }
+    }
+    __syncthreads();
+    // ---- backward of the 1-wide layer on the rows still in registers ----
+    float g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = sdzh[wv * 4 + i];
+    float* wr = wred + wv * 2 * K;
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+        const int k = lane * 4 + it * 256;
+        if (k < K) {
+            float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+            const float wk[4] = {c[it].x, c[it].y, c[it].z, c[it].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {               // rows in order: fixed summation order
+                const float x[4] = {a[it][i].x, a[it][i].y, a[it][i].z, a[it][i].w};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = g[i] * wk[e];
+                    if (mul_act) v[e] *= rs_act_grad(mul_act, x[e], x[e], 0.f);
+                    aw[e] = fmaf(g[i], x[e], aw[e]);
+                    ab[e] += v[e];
+                }
+                const int m = r0 + wv * 4 + i;
+                if (m < B) *reinterpret_cast<float4*>(dX + (long long)m * K + k) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            *reinterpret_cast<float4*>(wr + k) = make_float4(aw[0], aw[1], aw[2], aw[3]);
+            *reinterpret_cast<float4*>(wr + K + k) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+        }
+    }
+    __syncthreads();
+    float* prow = prow_all + (long long)blockIdx.x * 2 * K;
+    for (int col = threadIdx.x; col < 2 * K; col += 256)
+        prow[col] = ((wred[col] + wred[2 * K + col]) + wred[4 * K + col]) + wred[6 * K + col];      // wave order
+}
+
 // dst[b] = act(z[b])-style pointwise helpers on vectors -------------------------------------
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, long long n,
                                                       int act, const float* __restrict__ slope) {
@@ -507,6 +613,29 @@ int rs_head_fwd_bce(const float* X, int B, int K, const float* w, const float* b
     hipLaunchKernelGGL(head_fwd_bce_kernel, dim3(rs_cdiv(B, HEAD_ROWS)), dim3(256), 0, stream, X, B, K, w, bias, act, z0, z1,
                        labels_f32, labels_i64, grad_scale, h_out, loss_out, dz_out, sum_dz_out, dzh_out, sum_dzh_out, ws, sem);
     RS_CHECK_LAUNCH("rs_head_fwd_bce");
+    return RS_OK;
+}
+
+// rs_head_fwd_bce (sem == NULL form: batch sums left in ws[4g + {0,1,2}]) and rs_head_bwd in one launch; X is read
+// once.  part: [rs_head_bwd_rows(B), 2K] as for rs_head_bwd.  K % 4 == 0, K <= 1024.
+int rs_head_fwd_bwd(const float* X, int B, int K, const float* w, const float* bias, int act, const float* z0,
+                    const float* z1, const float* labels_f32, const int64_t* labels_i64, float grad_scale, float* h_out,
+                    float* dz_out, float* dzh_out, float* ws, int mul_act, float* dX, float* part, hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && K > 0 && X && w && ws && dX && part, "rs_head_fwd_bwd: bad arguments");
+    RS_CHECK_ARG((K & 3) == 0 && K <= 1024 && ((((uintptr_t)X | (uintptr_t)w | (uintptr_t)dX) & 15) == 0),
+                 "rs_head_fwd_bwd: K %% 4, K <= 1024 and 16-byte alignment");
+    RS_CHECK_ARG((labels_f32 != nullptr) != (labels_i64 != nullptr), "rs_head_fwd_bwd: pass exactly one label array");
+    RS_CHECK_ARG(z0 || !z1, "rs_head_fwd_bwd: z1 without z0");
+    RS_CHECK_ARG(act >= RS_ACT_NONE && act <= RS_ACT_LEAKYRELU, "rs_head_fwd_bwd: activation %d not fusable", act);
+    RS_CHECK_ARG(mul_act >= RS_ACT_NONE && mul_act <= RS_ACT_LEAKYRELU, "rs_head_fwd_bwd: activation %d not fusable", mul_act);
+    const dim3 grid(rs_cdiv(B, HEAD_ROWS)), block(256);
+    const size_t smem = (size_t)8 * K * sizeof(float);
+    const int ki = rs_cdiv(K, 256);
+#define RS_HEAD_FB(KI) hipLaunchKernelGGL(head_fwd_bwd_kernel<KI>, grid, block, smem, stream, X, B, K, w, bias, act, z0, z1, \
+                                          labels_f32, labels_i64, grad_scale, h_out, dz_out, dzh_out, ws, mul_act, dX, part)
+    if (ki == 1) RS_HEAD_FB(1); else if (ki == 2) RS_HEAD_FB(2); else if (ki == 3) RS_HEAD_FB(3); else RS_HEAD_FB(4);
+#undef RS_HEAD_FB
+    RS_CHECK_LAUNCH("rs_head_fwd_bwd");
     return RS_OK;
 }
 

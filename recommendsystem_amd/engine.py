@@ -342,7 +342,20 @@ class FusedTrainer:
         lastb = self.blocks[-1] if self.blocks else None
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
         csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None
-        if head_fast:
+        head_prev = self.blocks[-2] if head_fast and len(self.blocks) > 1 else None
+        head_fuse_prev = head_prev is not None and not head_prev.normalization and head_prev._act in (1, 2, 3)
+        head_both = head_fast and ctx["head_in"].shape[1] <= 1024
+        if head_both:
+            # the 1-wide last block, the loss, dL/dlogit and the block's backward in one launch
+            head = ops.head_fwd_bwd(ctx["head_in"], lastb.fc.weight.data.view(-1), lastb.fc.bias.data, lastb._act, parts,
+                                    labels, csp, dW_out=self.gviews[id(lastb.fc.weight)].view(-1),
+                                    grad_scale=self._grad_scale(),
+                                    sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None,
+                                    sum_dzh_out=self.gviews[id(lastb.fc.bias)],
+                                    mul_act=head_prev._act if head_fuse_prev else 0,
+                                    dbp_out=self.gviews[id(head_prev.fc.bias)] if head_fuse_prev else None)
+            parts = parts + [head["h"]]
+        elif head_fast:
             # the 1-wide last block, the loss and dL/dlogit in one launch
             head = ops.head_fwd_bce(ctx["head_in"], lastb.fc.weight.data.view(-1), lastb.fc.bias.data, lastb._act, parts,
                                     labels, grad_scale=self._grad_scale(),
@@ -381,9 +394,12 @@ class FusedTrainer:
                 prev = self.blocks[top - 1] if top > 0 else None
                 fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
                 # dX, dW of the head and (when the previous act' is fused) the previous block's bias gradient
-                dh = ops.head_bwd(head["dzh"], lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0, csp,
-                                  dW_out=self.gviews[id(lastb.fc.weight)].view(-1),
-                                  dbp_out=self.gviews[id(prev.fc.bias)] if fuse_prev else None)
+                if head_both:
+                    dh = head["dx"]
+                else:
+                    dh = ops.head_bwd(head["dzh"], lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0, csp,
+                                      dW_out=self.gviews[id(lastb.fc.weight)].view(-1),
+                                      dbp_out=self.gviews[id(prev.fc.bias)] if fuse_prev else None)
                 dz_ready = db_done = fuse_prev
                 top -= 1
             for i in range(top, -1, -1):

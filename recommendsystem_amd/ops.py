@@ -421,6 +421,54 @@ def head_fwd_bce(x: torch.Tensor, w: torch.Tensor, bias, act: int, parts, labels
     return out
 
 
+def head_fwd_bwd(x: torch.Tensor, w: torch.Tensor, bias, act: int, parts, labels: torch.Tensor, defer: "ColsumParts",
+                 dW_out: torch.Tensor, grad_scale=1.0, sum_dz_out=None, sum_dzh_out=None, mul_act: int = 0, dbp_out=None,
+                 ws: Optional[Workspace] = None):
+    """head_fwd_bce(..., defer=defer) and head_bwd(...) in one launch (x is read once; x.shape[1] <= 1024).
+    Returns dict(loss [1], dz [B], dzh [B], h [B], dx [B, K]); loss, the batch sums, dW_out and dbp_out are valid
+    after defer.finish()."""
+    _chk(x, torch.float32, "x")
+    B, K = x.shape
+    _chk(w, torch.float32, "w")
+    if w.numel() != K:
+        raise RSError("head_fwd_bwd: weight length differs from the input width")
+    parts = [p.reshape(-1) for p in parts if p is not None]
+    if len(parts) > 2:
+        raise RSError("head_fwd_bwd: at most two other logit parts")
+    for p in parts:
+        _chk(p, torch.float32, "logit part", (B,))
+    parts = parts + [None] * (2 - len(parts))
+    lf = li = None
+    if labels.dtype == torch.float32:
+        lf = labels
+    elif labels.dtype == torch.int64:
+        li = labels
+    else:
+        raise RSError(f"head_fwd_bwd: labels must be float32 or int64, got {labels.dtype}")
+    _chk(labels, labels.dtype, "labels", (B,))
+    dev = x.device
+    ws = ws or default_workspace(dev)
+    h = _lib.lib()
+    wbuf = ws.get("head_ws", h.rs_head_workspace_floats(B, K))
+    rows = h.rs_head_bwd_rows(B)
+    part = defer.buffer(rows * 2 * K)
+    out = {k: torch.empty(B, dtype=torch.float32, device=dev) for k in ("dz", "dzh", "h")}
+    out["loss"] = torch.empty(1, dtype=torch.float32, device=dev)
+    out["dx"] = torch.empty_like(x)
+    call("rs_head_fwd_bwd", ptr(x), B, K, ptr(w), ptr(bias), int(act), ptr(parts[0]), ptr(parts[1]), ptr(lf), ptr(li),
+         float(grad_scale), ptr(out["h"]), ptr(out["dz"]), ptr(out["dzh"]), ptr(wbuf), int(mul_act), ptr(out["dx"]),
+         ptr(part), stream())
+    defer.add(wbuf, rows, 1, 4, dest=out["loss"], offset=0)
+    if sum_dz_out is not None:
+        defer.add(wbuf, rows, 1, 4, dest=sum_dz_out, offset=1)
+    if sum_dzh_out is not None:
+        defer.add(wbuf, rows, 1, 4, dest=sum_dzh_out, offset=2)
+    defer.add(part, rows, K, 2 * K, dest=dW_out, offset=0)
+    if dbp_out is not None:
+        defer.add(part, rows, K, 2 * K, dest=dbp_out, offset=K)
+    return out
+
+
 def head_bwd(dzh: torch.Tensor, w: torch.Tensor, x: torch.Tensor, mul_act: int, parts: "ColsumParts",
              dW_out: torch.Tensor, dbp_out=None) -> torch.Tensor:
     """Backward of the 1-wide layer; returns dx and registers the partial sums of dW_out [K] (and of dbp_out [K] =

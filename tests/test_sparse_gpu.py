@@ -324,6 +324,42 @@ def test_fused_head_both_forms_match_torch(B, K):
         torch.testing.assert_close(s_dzh.cpu()[0], b.grad[0], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,K,mul_act", [(4096, 256, 1), (37, 64, 0), (1000, 512, 3), (130, 1024, 2), (50, 700, 1)])
+def test_head_forward_and_backward_in_one_launch(B, K, mul_act):
+    """rs_head_fwd_bwd against the two separate launches: same h / dz / dzh / dX bit for bit, sums to 1e-5."""
+    from recommendsystem_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(B * 7 + K)
+    x = torch.randn(B, K, generator=g).to(dev)
+    if mul_act == 1:
+        x = torch.relu(x)                  # x is the previous block's output h_prev; act' is taken from it
+    elif mul_act == 2:
+        x = torch.tanh(x)
+    w = (torch.randn(K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(1, generator=g).to(dev)
+    z0 = torch.randn(B, generator=g).to(dev)
+    y = (torch.rand(B, generator=g) < 0.3).long().to(dev)
+    ws = ops.default_workspace(dev)
+    res = []
+    for both in (False, True):
+        csp = ops.ColsumParts(ws)
+        s_dz, s_dzh = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        dW, dbp = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+        if both:
+            out = ops.head_fwd_bwd(x, w, b, 3, [z0], y, csp, dW_out=dW, grad_scale=0.5, sum_dz_out=s_dz,
+                                   sum_dzh_out=s_dzh, mul_act=mul_act, dbp_out=dbp)
+            dx = out["dx"]
+        else:
+            out = ops.head_fwd_bce(x, w, b, 3, [z0], y, grad_scale=0.5, sum_dz_out=s_dz, sum_dzh_out=s_dzh, defer=csp)
+            dx = ops.head_bwd(out["dzh"], w, x, mul_act, csp, dW_out=dW, dbp_out=dbp)
+        csp.finish()
+        res.append((out["h"], out["dz"], out["dzh"], dx, out["loss"], s_dz, s_dzh, dW, dbp))
+    for i in range(4):
+        assert torch.equal(res[0][i], res[1][i]), i
+    for i in range(4, 9):
+        torch.testing.assert_close(res[0][i], res[1][i], rtol=1e-5, atol=1e-7)
+
+
 def test_bce_head_matches_torch():
     from recommendsystem_amd import ops
     g = torch.Generator().manual_seed(4)
