@@ -338,7 +338,7 @@ __device__ __forceinline__ int list_bound(const unsigned* list, int len, unsigne
     return lo;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void lists_rank_kernel(SortArgs a, unsigned long long* merged64) {
+__global__ __launch_bounds__(SORT_THREADS) void lists_rank_kernel(SortArgs a, int max_entries, unsigned long long* merged64) {
     extern __shared__ __attribute__((aligned(16))) unsigned lkeys[];             // [sum of the field's list lengths]
     __shared__ int lbase[MERGE_MAX_LISTS + 1];
     const int f = blockIdx.x / a.nsrc, s = blockIdx.x % a.nsrc;
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(SORT_THREADS) void lists_rank_kernel(SortArgs a, un
         lbase[a.nsrc] = acc;
     }
     __syncthreads();
+    if (lbase[a.nsrc] > max_entries) return;             // more entries than the caller sized the LDS for: leave the field alone
     const long long V = a.vocab[f];
     for (int o = 0; o < a.nsrc; ++o) {
         const int cnt = lbase[o + 1] - lbase[o], off = a.sub_off[o * a.F + f];
@@ -1061,7 +1062,7 @@ int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int
         }
         reserved = MERGE_MAX_ENTRIES * sizeof(unsigned);
     }
-    hipLaunchKernelGGL(lists_rank_kernel, dim3(F * nsrc), dim3(SORT_THREADS), rsm, stream, a, merged64);
+    hipLaunchKernelGGL(lists_rank_kernel, dim3(F * nsrc), dim3(SORT_THREADS), rsm, stream, a, max_entries, merged64);
     const int it = max_entries <= 4096 ? 1 : (max_entries <= 8192 ? 2 : 4);
     const int tiles = rs_cdiv(max_entries, SORT_THREADS * it);
     const size_t tsm = (32 + SORT_THREADS) * sizeof(int);
