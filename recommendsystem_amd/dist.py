@@ -245,8 +245,12 @@ class HipShardKernels:
         self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
                              g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
 
-    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1):
-        self.plan_own.update(opt, hyper, scal, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
+    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, dense=None):
+        """Touched-rows step on the shard; dense = (w, g, m, v): the flat dense step in the same launch."""
+        if dense is not None:
+            self.plan_own.update_with_dense(opt, hyper, scal, *dense, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
+        else:
+            self.plan_own.update(opt, hyper, scal, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
 
     @property
     def n_own_partials(self):
@@ -373,6 +377,7 @@ class DistributedTrainer(FusedTrainer):
         self.bucket_slack = bucket_slack
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
+        self._update_shares_launch = True
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments
@@ -439,12 +444,13 @@ class DistributedTrainer(FusedTrainer):
         P[:plan.n_partials].zero_()
         P[0:1].copy_(self.flat_g_ext[-4:-3])
 
-    def _embed_update(self, plan):
+    def _embed_update(self, plan, with_dense=False):
         # `plan` is the base class's per-batch-size plan (its partial buffer carries the norm); the update
         # runs on the owner-side plan of the exchange
         ex = self._ex[plan.cap]
         ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
-                    self.shard1_m, self.shard1_v)
+                    self.shard1_m, self.shard1_v,
+                    dense=(self.flat_w, self.flat_g, self.flat_m, self.flat_v) if with_dense else None)
 
     # ---- HIP-graph segments between the collectives --------------------------------------------------
     def _capture(self, idx, labels):
@@ -604,6 +610,7 @@ class ReplicatedTablesTrainer(FusedTrainer):
         kw.pop("mode", None)
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
+        self._update_shares_launch = True
         self._rp = {}
         self.comm.broadcast(self.flat_w, 0)
         for t in self.tables:

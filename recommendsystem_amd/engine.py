@@ -126,6 +126,7 @@ class FusedTrainer:
         # 1/True: index sort and weight-gradient GEMMs on side streams; 2: only the index sort
         self.overlap = int(overlap)
         self._sort_can_fork = True
+        self._update_shares_launch = False     # subclasses whose _embed_update(with_dense=True) does both optimizer steps
         self.side_w = torch.cuda.Stream(device=dev)
         self.side_sort = torch.cuda.Stream(device=dev)
         self.ws_w = ops.Workspace(dev)
@@ -490,11 +491,12 @@ class FusedTrainer:
             loss = self._add_reg_to_loss(loss)
 
         # ---- optimizer --------------------------------------------------------------------------
-        if fuse:
+        both = fuse or (self._update_shares_launch and self.mode == "sparse")     # dense and touched-row steps in one launch
+        if both:
             self._embed_update(plan, with_dense=True)
         else:
             ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
-        if fuse:
+        if both:
             pass
         elif self.mode == "sparse":
             self._embed_update(plan)
