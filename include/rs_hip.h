@@ -253,7 +253,8 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
  * global norm of clip_grad_norm_ (BaseModel.py:148).  cs_*: up to 8 column-sum finishes (the arguments of
  * rs_colsum_finish_multi; cs_count may be 0) that run beside its first launch -- the bias gradients of the dense
  * backward, which may lie inside `dense`; sk_*: likewise up to 8 split-K reductions (the arguments of
- * rs_splitk_reduce_multi) -- its weight gradients. */
+ * rs_splitk_reduce_multi) -- its weight gradients.  dense may be NULL with n_dense_partials = 0 (only the finishes
+ * ride along). */
 int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                                float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,

@@ -1197,7 +1197,8 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
 // (dense_partials[0 .. n_dense_partials), one per extra workgroup) and, in the launch of its first phase, the
 // cs_count column-sum finishes of rs_colsum_finish_multi and the sk_count split-K reductions of rs_splitk_reduce_multi
 // (cs_* / sk_* as those entry points' arguments; the counts may be 0).  Their outputs may be part of `dense`: the
-// second launch starts after the first has ended.
+// second launch starts after the first has ended.  dense == nullptr with n_dense_partials == 0: no dense buffer, only the
+// finishes ride along.
 int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                                float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
@@ -1225,7 +1226,8 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce_sumsq: dfm needs S and emb");
     RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce_sumsq: chunk_sum1/rowgrad1 mismatch");
     RS_CHECK_ARG(Fdiv > 0, "rs_sparse_bwd_reduce_sumsq: Fdiv must be positive");
-    RS_CHECK_ARG(dense && dense_partials && dense_n >= 0 && n_dense_partials > 0, "rs_sparse_bwd_reduce_sumsq: bad dense arguments");
+    RS_CHECK_ARG((dense && dense_partials && dense_n >= 0 && n_dense_partials > 0) || (!dense && n_dense_partials == 0),
+                 "rs_sparse_bwd_reduce_sumsq: bad dense arguments");
     ReduceArgs a{};
     int VEC;
     RS_CHECK_ARG(fill_reduce(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_bwd_reduce_sumsq: unsupported d=%d", d);

@@ -226,9 +226,11 @@ class HipShardKernels:
         call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d, ptr(rows),
              ptr(rows1), ptr(emb), ptr(lr1), stream())
 
-    def reduce_local(self, gout, dfm, S, emb, dlr):
-        """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1)."""
-        self.plan_req.reduce(self.scratch_partials, gout=gout, dfm=dfm, S=S, emb=emb, dlr=dlr, Fdiv=self.F)
+    def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
+        """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1).  colsum / splitk: pending
+        column-sum and split-K finishes of the dense backward that ride in the first launch (SparsePlan.reduce)."""
+        self.plan_req.reduce(self.scratch_partials, gout=gout, dfm=dfm, S=S, emb=emb, dlr=dlr, Fdiv=self.F,
+                             colsum=colsum, splitk=splitk)
 
     def pack(self, route, grads, grads1):
         call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d,
@@ -338,10 +340,13 @@ class ShardedExchange:
             c.all_to_all(self.rows1_r, self.rows1_s)
         k.expand(self.route, self.rows_r, self.rows1_r, emb_out, lr1_out)
 
-    def backward(self, gout, dfm, S, emb, dlr, own_partials):
+    def backward(self, gout, dfm, S, emb, dlr, own_partials, colsum=None, splitk=None):
         """Per-entry gradient terms of the local batch -> summed row gradients on the owners."""
         k, c = self.k, self.comm
-        k.reduce_local(gout, dfm, S, emb, dlr)
+        if colsum is not None or splitk is not None:
+            k.reduce_local(gout, dfm, S, emb, dlr, colsum=colsum, splitk=splitk)
+        else:
+            k.reduce_local(gout, dfm, S, emb, dlr)
         k.pack(self.route, self.g_s, self.g1_s)
         if self.with_emb:
             c.all_to_all(self.g_r, self.g_s)
@@ -378,6 +383,7 @@ class DistributedTrainer(FusedTrainer):
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
+        self._reduce_carries_finishes = True
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments
@@ -426,12 +432,12 @@ class DistributedTrainer(FusedTrainer):
             r["lr"] = ops.rowdot_fwd(lr1, self.ones_F, self.lrm.bias.data, 0)     # sum_f w_f[idx] + bias
         return r
 
-    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already):
+    def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None, splitk=None):
         B = idx.shape[1]
         ex = self.exchange(B)
         ex.backward(gout, dz if self.has_fm else None, ctx["S"],
                     ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
-                    ex.own_partials)
+                    ex.own_partials, colsum=colsum, splitk=splitk)
         # ||g||^2 of the owned rows (every rank owns disjoint rows) rides behind the dense gradients in the
         # one all-reduce of the step
         ops.colsum(ex.own_partials.view(-1, 1), out=self.flat_g_ext[-4:-3])
@@ -611,6 +617,7 @@ class ReplicatedTablesTrainer(FusedTrainer):
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
+        self._reduce_carries_finishes = True
         self._rp = {}
         self.comm.broadcast(self.flat_w, 0)
         for t in self.tables:
@@ -629,7 +636,8 @@ class ReplicatedTablesTrainer(FusedTrainer):
         B = idx.shape[1]
         if plan.cap != B:
             raise RSError("replicated tables: the plan capacity must equal the batch size")
-        FusedTrainer._embed_backward(self, plan, idx, gout, dz, ctx, sorted_already)     # one gradient per distinct row
+        FusedTrainer._embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, colsum=colsum,
+                                     splitk=splitk)                                    # one gradient per distinct row
         rx = self._replica(B)
         rx.merge(plan.seg_rows(), plan.counts()[:, 2], plan.rowgrad if self.has_emb else None,
                  plan.rowgrad1 if self.has_lr else None)

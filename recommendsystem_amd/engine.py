@@ -127,6 +127,7 @@ class FusedTrainer:
         self.overlap = int(overlap)
         self._sort_can_fork = True
         self._update_shares_launch = False     # subclasses whose _embed_update(with_dense=True) does both optimizer steps
+        self._reduce_carries_finishes = False  # subclasses whose _embed_backward takes the pending finishes along
         self.side_w = torch.cuda.Stream(device=dev)
         self.side_sort = torch.cuda.Stream(device=dev)
         self.ws_w = ops.Workspace(dev)
@@ -440,7 +441,8 @@ class FusedTrainer:
                 keep.append(dh)
             # the bias-gradient finishes and the weight-gradient split-K reduces: beside the first launch of the
             # embedding reduction when that is fused
-            if self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse":
+            carry = self._reduce_carries_finishes and not overlap and self.mode == "sparse"
+            if carry or (self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"):
                 pending_colsum = csp.hand_over()
                 pending_splitk = skp.hand_over() if skp is not None else None
             else:
@@ -461,6 +463,9 @@ class FusedTrainer:
         if fuse:
             self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p,
                                  colsum=pending_colsum, splitk=pending_splitk)
+        elif pending_colsum is not None or pending_splitk is not None:
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, colsum=pending_colsum,
+                                 splitk=pending_splitk)
         else:
             self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early)
 

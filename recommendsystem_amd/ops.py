@@ -627,17 +627,17 @@ class SparsePlan:
             raise RSError("sparse backward: norm_partials too small")
         for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
             _chk(t, torch.float32, n)
-        if dense is not None:
-            _chk(dense, torch.float32, "dense")
-            _chk(dense_partials, torch.float32, "dense_partials")
+        if dense is not None or colsum is not None or splitk is not None:
+            if dense is not None:
+                _chk(dense, torch.float32, "dense")
+                _chk(dense_partials, torch.float32, "dense_partials")
             call("rs_sparse_bwd_reduce_sumsq", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm),
                  ptr(S), ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1),
-                 ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense), dense.numel(),
-                 ptr(dense_partials), dense_partials.numel(), *(colsum or (None, None, None, None, None, 0)),
+                 ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense),
+                 dense.numel() if dense is not None else 0, ptr(dense_partials if dense is not None else None),
+                 dense_partials.numel() if dense is not None else 0, *(colsum or (None, None, None, None, None, 0)),
                  *(splitk or (None, None, None, None, 0)), stream())
             return
-        if colsum is not None or splitk is not None:
-            raise RSError("sparse backward: column-sum finishes ride only with the dense-norm form of the reduction")
         call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(norm_partials), stream())
