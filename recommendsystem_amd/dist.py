@@ -445,10 +445,9 @@ class DistributedTrainer(FusedTrainer):
 
     def _reduce_dense_grads(self):
         self.comm.all_reduce(self.flat_g_ext)
-        plan = self._cur_plan
-        P = plan.partials
-        P[:plan.n_partials].zero_()
-        P[0:1].copy_(self.flat_g_ext[-4:-3])
+        # the base plan's table partials are written by nobody on this path (the exchange reduces on its own plans), so
+        # they stay zero from allocation on; slot 0 carries the all-reduced ||g||^2 of the sharded tables
+        self._cur_plan.partials[0:1].copy_(self.flat_g_ext[-4:-3])
 
     def _embed_update(self, plan, with_dense=False):
         # `plan` is the base class's per-batch-size plan (its partial buffer carries the norm); the update
