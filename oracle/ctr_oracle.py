@@ -229,10 +229,34 @@ class OracleMLPBlock(nn.Module):
         return _activation(self.activation, z, pw)
 
 
+class OracleResidualBlock(nn.Module):
+    """Same parameters and forward as model/utils/Layers.py:50-94 (dropout 0): identity (or downsample(x)) +
+    act(norm(fc(x))); normalisation is mandatory there (Layers.py:68-73)."""
+
+    def __init__(self, in_dim, out_dim, activation="ReLU", normalization="bn"):
+        super().__init__()
+        self.fc = nn.Linear(in_dim, out_dim)
+        self.activation = activation.lower()
+        self.normalization = normalization
+        if normalization == "bn":
+            self.norm_layer = nn.BatchNorm1d(out_dim)
+        elif normalization == "ln":
+            self.norm_layer = nn.LayerNorm(out_dim)
+        else:
+            raise ValueError("normalization must be either 'bn' or 'ln'")
+        self.downsample = nn.Linear(in_dim, out_dim) if in_dim != out_dim else None
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], -1)
+        out = _activation(self.activation, self.norm_layer(self.fc(x)))
+        identity = x if self.downsample is None else self.downsample(x)
+        return identity + out
+
+
 class OracleCTRModel(nn.Module):
     """Per-field nn.Embedding tables + one of the reference's model heads.
 
-    kind: "lr" | "fm" | "deepfm" | "dnn" | "widedeep" | "ffm" | "pnn" | "nfm" | "afm" | "dcn".
+    kind: "lr" | "fm" | "deepfm" | "dnn" | "widedeep" | "deepcrossing" | "ffm" | "pnn" | "nfm" | "afm" | "dcn".
     Outputs LOGITS (B, 1);
     the training step applies sigmoid before BCE the way model/LR/LR.py:29-33
     does.  Embedding tables follow model/utils/Layers.py:118-135 (one
@@ -250,6 +274,9 @@ class OracleCTRModel(nn.Module):
         self.dim = dim
         self.emb = nn.ModuleDict()
         self.emb1 = nn.ModuleDict()
+        # model/DeepCrossing/DeepCrossing.py has no LinearRegression_layer: its only tables are BaseModel's
+        # embedding_layer (BaseModel.py:47)
+        self.has_lr_tables = kind != "deepcrossing"
         for c in self.cols:
             v = feature_map[c]["vocab_size"]
             e = nn.Embedding(v, dim, padding_idx=0)
@@ -260,16 +287,27 @@ class OracleCTRModel(nn.Module):
                 e.weight[0].zero_()
                 e1.weight[0].zero_()
             self.emb[c] = e
-            self.emb1[c] = e1
+            if self.has_lr_tables:
+                self.emb1[c] = e1
         if mirror_unused:
             # The reference builds two Embedding_layer objects per model (BaseModel.py:47 and
             # Layers.py:102), each with d-dim AND 1-dim tables; half of them never see a batch
             # but they are parameters: L2 regularisation and clip_grad_norm_ include them.
-            self.unused_emb = nn.ModuleDict({c: nn.Embedding(feature_map[c]["vocab_size"], dim, padding_idx=0)
-                                             for c in self.cols})
+            if self.has_lr_tables:
+                self.unused_emb = nn.ModuleDict({c: nn.Embedding(feature_map[c]["vocab_size"], dim, padding_idx=0)
+                                                 for c in self.cols})
             self.unused_emb1 = nn.ModuleDict({c: nn.Embedding(feature_map[c]["vocab_size"], 1, padding_idx=0)
                                               for c in self.cols})
-        self.bias = nn.Parameter(torch.zeros(1))
+        if self.has_lr_tables:
+            self.bias = nn.Parameter(torch.zeros(1))
+        if kind == "deepcrossing":                  # model/DeepCrossing/DeepCrossing.py:15-26
+            dims = [len(self.cols) * dim] + list(hidden) + [1]
+            self.mlp = nn.Sequential(*[OracleResidualBlock(dims[i], dims[i + 1], activation, normalization)
+                                       for i in range(len(dims) - 1)])
+            for m in self.mlp.modules():            # model/utils/BaseModel.py:79-91
+                if type(m) is nn.Linear:
+                    nn.init.xavier_normal_(m.weight)
+                    m.bias.data.fill_(0)
         if kind in ("deepfm", "dnn", "widedeep"):
             dims = [len(self.cols) * dim] + list(hidden) + [1]
             # model/DeepFM/DeepFM.py:25-38: every layer, the 1-wide head included, is an MLPBlock
@@ -336,6 +374,8 @@ class OracleCTRModel(nn.Module):
             return self.deep(e)
         if self.kind == "widedeep":                 # model/WideDeep/WideDeep.py:43-51
             return self.lr(x) + self.deep(e)
+        if self.kind == "deepcrossing":             # model/DeepCrossing/DeepCrossing.py:32-36
+            return self.mlp(e)
         B, nf, d = e.shape
         if self.kind == "ffm":                      # model/FFM/FFM.py:32-40
             xm = torch.stack([x[c].long() for c in self.cols], dim=1)

@@ -290,7 +290,12 @@ class RefModel(RB.BaseModel):
         super().__init__(model_name=kind, dataRecorder=dr, learning_rate=lr, optimizer_type=optimizer_type,
                          gpu=-1, emb_regular=regular, net_regular=regular)
         self.kind = kind
-        self.lr_layer = RL.LinearRegression_layer(dr)
+        if kind != "deepcrossing":
+            self.lr_layer = RL.LinearRegression_layer(dr)
+        if kind == "deepcrossing":          # model/DeepCrossing/DeepCrossing.py:15-26
+            dims = [dr.input_dim] + list(hidden) + [1]
+            self.mlp = nn.Sequential(*[RL.ResidualMLPBlock(dims[i], dims[i + 1], activation, normalization)
+                                       for i in range(len(dims) - 1)])
         if kind == "deepfm":
             dims = [dr.input_dim] + list(hidden)
             layers = [RL.MLPBlock(dims[i], dims[i + 1], activation, normalization) for i in range(len(dims) - 1)]
@@ -303,6 +308,8 @@ class RefModel(RB.BaseModel):
 
     def logits(self, x):
         x = self.features_to_divice(x)
+        if self.kind == "deepcrossing":     # model/DeepCrossing/DeepCrossing.py:32-36 (before its sigmoid)
+            return self.mlp(self.embedding_layer(x))
         lr = lr_from_modules(self.lr_layer.scalar, self.lr_layer.bias, x)
         if self.kind == "lr":
             return lr
@@ -320,11 +327,12 @@ class RefModel(RB.BaseModel):
 
 
 def gen_train(kind, optimizer_type, regular, fname, hidden=(), normalization=None, scale_tables=1.0,
-              lr=1e-3, steps=3, bs=16, vocabs=(11, 7, 50, 3, 200), dim=4):
+              lr=1e-3, steps=3, bs=16, vocabs=(11, 7, 50, 3, 200), dim=4, activation="ReLU", slim=False):
     random_all(2021)
     gen = torch.Generator().manual_seed(17)
     dr = recorder(list(vocabs), 2, dim, bs)
-    m = RefModel(kind, dr, lr, optimizer_type, hidden=hidden, normalization=normalization, regular=regular)
+    m = RefModel(kind, dr, lr, optimizer_type, hidden=hidden, activation=activation, normalization=normalization,
+                 regular=regular)
     if scale_tables != 1.0:      # larger embeddings so second-order terms matter in the test
         with torch.no_grad():
             for n, p in m.named_parameters():
@@ -333,7 +341,8 @@ def gen_train(kind, optimizer_type, regular, fname, hidden=(), normalization=Non
     m.train()
     d = {"feature_map": json.dumps(dr.feature_map), "features": json.dumps(dr.features), "dim": dim,
          "kind": kind, "optimizer": optimizer_type, "lr": lr, "regular": -1.0 if regular is None else regular,
-         "hidden": json.dumps(list(hidden)), "normalization": json.dumps(normalization), "steps": steps}
+         "hidden": json.dumps(list(hidden)), "normalization": json.dumps(normalization), "steps": steps,
+         "activation": activation}
     for n, p in m.state_dict().items():
         d[f"init.{n}"] = npy(p)
     for s in range(steps):
@@ -349,7 +358,7 @@ def gen_train(kind, optimizer_type, regular, fname, hidden=(), normalization=Non
             d[f"step{s}.x.{c}"] = npy(x[c])
         d[f"step{s}.label"] = npy(y["label"])
         for n, p in m.named_parameters():
-            if p.grad is not None:                   # unused tables keep grad None and are not stepped
+            if p.grad is not None and not slim:      # unused tables keep grad None and are not stepped
                 d[f"step{s}.grad.{n}"] = npy(p.grad)     # after clip_grad_norm_ (in place)
         for n, p in m.state_dict().items():
             d[f"step{s}.after.{n}"] = npy(p)
@@ -377,6 +386,16 @@ if __name__ == "__main__":
     gen_train("deepfm", "SGD", None, "train_deepfm_sgd_bn.npz", hidden=(16, 8), normalization="bn",
               scale_tables=1000.0, lr=0.05)
     gen_train("deepfm", "AdamW", 1e-4, "train_deepfm_adamw_reg.npz", hidden=(16, 8), scale_tables=1000.0)
+    # residual stacks (DeepCrossing): ReLU+BatchNorm under SGD, tanh+LayerNorm under Adam
+    gen_train("deepcrossing", "SGD", None, "train_deepcrossing_sgd_bn.npz", hidden=(16, 8), normalization="bn",
+              scale_tables=1000.0, lr=0.05)
+    gen_train("deepcrossing", "Adam", None, "train_deepcrossing_adam_ln.npz", hidden=(16, 8), normalization="ln",
+              scale_tables=1000.0, activation="tanh")
+    # longer traces: rows stay absent from the batch for several steps in a row while their Adam moments still move them
+    gen_train("deepfm", "Adam", None, "train_deepfm_adam_long.npz", hidden=(16, 8), scale_tables=1000.0, steps=12,
+              bs=8, slim=True)
+    gen_train("deepfm", "AdamW", None, "train_deepfm_adamw_long.npz", hidden=(16, 8), scale_tables=1000.0, steps=8,
+              bs=8, slim=True)
     gen_state_dict_layout()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot, sorted(os.listdir(OUT)))

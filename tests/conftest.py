@@ -50,7 +50,8 @@ def oracle_model_from_golden(g, mirror_unused=True):
     kind = str(g["kind"])
     hidden = json.loads(str(g["hidden"]))
     norm = json.loads(str(g["normalization"]))
-    m = O.OracleCTRModel(kind, fm, feats, int(g["dim"]), hidden=hidden, normalization=norm,
+    act = str(g["activation"]) if "activation" in g else "ReLU"
+    m = O.OracleCTRModel(kind, fm, feats, int(g["dim"]), hidden=hidden, normalization=norm, activation=act,
                          mirror_unused=mirror_unused)
     load_oracle_state(m, g, "init.")
     return m

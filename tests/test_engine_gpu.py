@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 
 FIXTURES = ["train_lr_adam_reg.npz", "train_fm_sgd.npz", "train_deepfm_adam.npz", "train_deepfm_sgd_bn.npz",
             "train_deepfm_adamw_reg.npz"]
+# residual stacks (model/DeepCrossing/DeepCrossing.py:15-36): not part of the fused engine's model family
+RESIDUAL_FIXTURES = ["train_deepcrossing_sgd_bn.npz", "train_deepcrossing_adam_ln.npz"]
+LONG_FIXTURES = ["train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"]
 
 
 def build_model(g):
@@ -34,6 +37,10 @@ def build_model(g):
         m = models.LR(dr, float(g["lr"]), 0, **kw)
     elif kind == "fm":
         m = models.FM(dr, float(g["lr"]), 0, **kw)
+    elif kind == "deepcrossing":
+        m = models.DeepCrossing(dr, float(g["lr"]), 0, hidden_dim_list=json.loads(str(g["hidden"])),
+                                activation_func=str(g["activation"]), normalization=json.loads(str(g["normalization"])),
+                                **kw)
     else:
         m = models.DeepFM(dr, float(g["lr"]), 0, hidden_dim_list=json.loads(str(g["hidden"])),
                           normalization=json.loads(str(g["normalization"])), **kw)
@@ -42,6 +49,14 @@ def build_model(g):
     m.load_state_dict(sd)
     m.train()
     return m, feats
+
+
+def noise_driven(fname, name):
+    """train_deepcrossing_adam_ln.npz: the 1-wide last residual block normalises over one feature, so the gradients
+    of its fc and gamma are mathematically zero; the fixture holds torch's rounding noise there (1e-9 .. 1e-6), which
+    Adam turns into steps of up to lr.  Nothing downstream depends on them (the block's output is `beta`)."""
+    return fname == "train_deepcrossing_adam_ln.npz" and name in ("mlp.2.fc.weight", "mlp.2.fc.bias",
+                                                                   "mlp.2.norm_layer.weight")
 
 
 def compare_state(m, g, prefix, rtol=2e-5, atol=2e-7, only=None):
@@ -56,7 +71,7 @@ def compare_state(m, g, prefix, rtol=2e-5, atol=2e-7, only=None):
                                    msg=lambda s, name=name: f"{name}: {s}")
 
 
-@pytest.mark.parametrize("fname", FIXTURES)
+@pytest.mark.parametrize("fname", FIXTURES + RESIDUAL_FIXTURES + LONG_FIXTURES)
 def test_module_path_train_step(fname):
     g = load_golden(fname)
     m, feats = build_model(g)
@@ -69,12 +84,16 @@ def test_module_path_train_step(fname):
         torch.testing.assert_close(loss.detach().cpu(), torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
         for n, p in m.named_parameters():
             key = f"step{s}.grad.{n}"
+            if fname in LONG_FIXTURES:          # weights only
+                break
+            if noise_driven(fname, n):
+                continue
             if p.grad is None:
                 assert key not in g
             else:
                 torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(g[key]), rtol=1e-4, atol=5e-7,
                                            msg=lambda s_, n=n: f"{n}: {s_}")
-        compare_state(m, g, f"step{s}.after.")
+        compare_state(m, g, f"step{s}.after.", only=lambda name: not noise_driven(fname, name))
 
 
 @pytest.mark.parametrize("fname", FIXTURES)
@@ -92,6 +111,22 @@ def test_fused_engine_dense_mode(fname, graph):
         torch.testing.assert_close(loss.cpu()[0], torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
         compare_state(m, g, f"step{s}.after.")
     m.embedding_layer._tab.layout.check_indices()
+
+
+def test_touched_rows_step_on_residual_stack_sgd():
+    """The reference's train_step on a DeepCrossing stack (ReLU + BatchNorm residual blocks), replayed by the generic
+    touched-rows trainer: SGD has no state, so every step equals the reference's dense update."""
+    g = load_golden("train_deepcrossing_sgd_bn.npz")
+    m, feats = build_model(g)
+    m.use_sparse_step()
+    for s in range(int(g["steps"])):
+        x = golden_batch(g, feats, f"step{s}.x.")
+        y = {"label": torch.from_numpy(g[f"step{s}.label"])}
+        with torch.no_grad():                   # the fixture ran one extra training-mode forward per step
+            torch.testing.assert_close(m.logits(x).cpu(), torch.from_numpy(g[f"step{s}.logits"]), rtol=1e-5, atol=1e-6)
+        loss = m.train_step(x, y)
+        torch.testing.assert_close(loss.cpu().view(()), torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
+        compare_state(m, g, f"step{s}.after.")
 
 
 @pytest.mark.parametrize("fname", ["train_fm_sgd.npz", "train_deepfm_sgd_bn.npz"])

@@ -113,7 +113,9 @@ def test_interactions():
 
 
 @pytest.mark.parametrize("fname", ["train_lr_adam_reg.npz", "train_fm_sgd.npz", "train_deepfm_adam.npz",
-                                   "train_deepfm_sgd_bn.npz", "train_deepfm_adamw_reg.npz"])
+                                   "train_deepfm_sgd_bn.npz", "train_deepfm_adamw_reg.npz",
+                                   "train_deepcrossing_sgd_bn.npz", "train_deepcrossing_adam_ln.npz",
+                                   "train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"])
 def test_train_steps(fname):
     g = load_golden(fname)
     fm, feats = golden_feature_map(g)
@@ -134,6 +136,8 @@ def test_train_steps(fname):
         for k, v in have.items():
             torch.testing.assert_close(v, want[k], rtol=1e-5, atol=1e-7, msg=lambda s_, k=k: f"{k}: {s_}")
         grads = golden_state(g, f"step{s}.grad.")
+        if not grads:                       # the long traces keep weights only
+            continue
         for n, p in m.named_parameters():
             if p.grad is None:
                 assert n not in grads

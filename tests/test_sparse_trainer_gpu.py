@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import ctr_oracle as O
-from test_models_gpu import BATCH, VOCAB, build, key_to_oracle, make_oracle
+from test_models_gpu import BATCH, VOCAB, build, key_to_oracle, make_oracle, noise_driven
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,8 @@ CASES = [
     ("dcn", "SGD", 2, dict(hidden_dim_list=[32, 16], cross_layers_num=3, normalization="bn")),
     ("dcn", "Adam", 1, dict(hidden_dim_list=[32, 16], cross_layers_num=2, normalization=None)),
     ("widedeep", "SGD", 2, dict(hidden_dim_list=[32, 16], normalization="ln")),
+    ("deepcrossing", "SGD", 2, dict(hidden_dim_list=[32, 16], normalization="bn")),
+    ("deepcrossing", "Adam", 1, dict(hidden_dim_list=[32, 32], normalization="ln", activation_func="tanh")),
 ]
 
 
@@ -48,10 +50,10 @@ def test_sparse_step_matches_dense_oracle(use_graph, kind, optimizer, steps, kw)
         torch.testing.assert_close(loss.cpu().view(()), ref_loss.view(()), rtol=2e-5, atol=1e-6)
         osd = o.state_dict()
         for k, v in m.state_dict().items():
-            ok = key_to_oracle(k)
+            ok = key_to_oracle(k, kind)
             if kind == "nfm" and k == "linear.bias":
                 ok = "linear.bias"
-            if ok is None or not v.dtype.is_floating_point:
+            if ok is None or not v.dtype.is_floating_point or noise_driven(kind, kw, k):
                 continue
             atol = 5e-5 if optimizer in ("Adam", "Adagrad") else 5e-6
             torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
