@@ -294,6 +294,31 @@ int rs_opt_prepare(long long* step, float* hyper, rs_stream_t stream);
 int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
                         rs_stream_t stream);
 
+/* ---- dense Adam / AdamW semantics on tables that are stepped on touched rows only ---------------------------
+ * torch.optim.Adam / AdamW as the reference builds them (model/utils/BaseModel.py:64-72) step EVERY row of every
+ * nn.Embedding table on every batch (model/utils/Layers.py:132: dense gradients): a row absent from a batch gets a
+ * zero gradient, so its moments decay, AdamW shrinks it, and it keeps moving while its first moment is not zero.
+ * rs_sparse_update skips those rows; these entry points replay the skipped zero-gradient steps when a row is next
+ * read, so that lookups and updates see exactly the weights the reference would hold.
+ *   last [R] int32 (one per table, zero-initialised): optimizer steps already contained in (table, m, v) of a row.
+ *   step: the device step counter rs_clip_and_prepare increments (its value = steps taken so far).
+ *   bctab [tab_n] float2 from rs_adam_bc_table: {1/(1-beta1^k), 1/sqrt(1-beta2^k)} in double precision as torch's
+ *   host code computes them; steps beyond tab_n are computed on the fly.  kmax bounds the replay loop (the drift
+ *   terms decay like beta1^j; ceil(log(1e-12)/log(beta1)) is enough), the rest is applied in closed form.
+ * rs_adam_catchup: for every entry of the columnar batch idx [F,B], bring row row_offset[f]+idx[f,b] of table
+ *   (width d) and/or table1 (width 1) up to `*step` steps and mark it as containing *step + mark_ahead steps
+ *   (mark_ahead = 1 in a training step, whose rs_sparse_update will apply step *step + 1 to exactly these rows; 0 for
+ *   a forward-only pass).  Call it before the lookup.  The learning rate must not have changed since a row's last
+ *   step: call rs_adam_flush before changing hyper[0].
+ * rs_adam_flush: every row of one table up to *step (before evaluation, state_dict, a learning-rate change). */
+int rs_adam_bc_table(float* bctab, int tab_n, const float* hyper, rs_stream_t stream);
+int rs_adam_catchup(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, int B, int F, int d,
+                    float* table, float* m, float* v, int* last, float* table1, float* m1, float* v1, int* last1,
+                    int opt, const long long* step, int mark_ahead, const float* hyper, const float* bctab, int tab_n,
+                    int kmax, rs_stream_t stream);
+int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, int d, int opt, const long long* step,
+                  const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
+
 
 /* ---- row-sharded tables: device side of the all-to-all exchange (no reference counterpart: the
  * reference is single-device; semantics are those of Embedding_layer.forward / its backward on the

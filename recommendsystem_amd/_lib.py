@@ -56,6 +56,11 @@ _SIGS = {
     "rs_clip_coef": [c_f32p, I, F, c_f32p, c_stream],
     "rs_opt_prepare": [c_i64p, c_f32p, c_stream],
     "rs_clip_and_prepare": [c_f32p, I, F, c_f32p, c_i64p, c_f32p, c_stream],
+    # rowstate.hip
+    "rs_adam_bc_table": [c_f32p, I, c_f32p, c_stream],
+    "rs_adam_catchup": [c_i64p, c_i64p, c_i64p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p,
+                        I, c_i64p, I, c_f32p, c_f32p, I, I, c_stream],
+    "rs_adam_flush": [c_f32p, c_f32p, c_f32p, c_i32p, L, I, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
     # elementwise.hip
     "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F,
                     c_f32p, c_f32p, I, c_f32p, c_f32p, c_stream],

@@ -156,6 +156,21 @@ class BaseModel(nn.Module):
         self._engine = SparseTrainer(self, **kw)
         return self._engine
 
+    def _flush_engine(self):
+        """A touched-rows Adam trainer replays the skipped steps of a row only when the row is next read; before the
+        tables are read or written as a whole every row is brought up to date."""
+        eng = self._engine
+        if eng is not None and hasattr(eng, "flush"):
+            eng.flush()
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_engine()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._flush_engine()
+        return super().load_state_dict(*args, **kwargs)
+
     # ---- loops (BaseModel.py:98-173) ---------------------------------------------------------
     def fit(self):
         loader = self.dataRecorder.train_loader
@@ -213,6 +228,7 @@ class BaseModel(nn.Module):
 
     def evaluate(self, data_loader):
         self.eval()
+        self._flush_engine()
         with torch.no_grad():
             val_labels, val_preds = [], []
             for inputs, labels in data_loader:

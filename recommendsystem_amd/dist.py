@@ -380,6 +380,7 @@ class DistributedTrainer(FusedTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
+        kw.setdefault("exact_adam", False)
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
@@ -613,6 +614,7 @@ class ReplicatedTablesTrainer(FusedTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         kw.pop("mode", None)
+        kw.setdefault("exact_adam", False)
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
@@ -704,6 +706,7 @@ class DistributedSparseTrainer(SparseTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
+        kw.setdefault("exact_adam", False)
         super().__init__(model, **kw)
         self._shards = {}
         self._provider = _ShardedLookups(self)

@@ -12,10 +12,14 @@ sequence of HIP kernels with no host synchronisation, optionally replayed from a
 Two embedding-update modes:
 
 * ``mode="sparse"`` (default, the fast path): optimizer state and weights of touched rows only.
-  Identical to the reference's dense optimizers for SGD and Adagrad; for Adam/AdamW it is the
-  "lazy" variant (rows absent from a batch keep their weights and moments), which differs from
-  dense Adam on rows with non-zero momentum that the batch does not touch.  Needs
-  ``emb_regular`` to be off (an L2 term on the tables gives every row a gradient).
+  Identical to the reference's dense optimizers for SGD and Adagrad.  For Adam/AdamW a row absent
+  from a batch still moves in the reference (zero gradient, decaying moments, AdamW decay): with
+  ``exact_adam=True`` (default) every table carries a per-row step counter and the skipped
+  zero-gradient steps of a row are replayed right before it is next read (rs_adam_catchup), so
+  lookups, gradients and updates are those of the reference's dense optimizer; ``flush()`` brings
+  every row up to date (evaluate / state_dict / a learning-rate change do it).  ``exact_adam=False``
+  is the "lazy" variant (absent rows keep their weights and moments).  Needs ``emb_regular`` to be
+  off (an L2 term on the tables gives every row a gradient).
 * ``mode="dense"``: the reference's exact semantics -- row gradients are expanded into full-table
   gradients, L2 terms are added, and dense optimizer kernels sweep every table.  Used for
   bit-for-semantics parity tests and as the AUC reference for the sparse mode.
@@ -58,7 +62,8 @@ class _Fork:
 
 class FusedTrainer:
     def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
-                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = False):
+                 optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = False,
+                 exact_adam: bool = True):
         kind = getattr(model, "KIND", None)
         if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
@@ -78,6 +83,8 @@ class FusedTrainer:
             raise RSError("FusedTrainer(mode='sparse'): emb_regular puts a gradient on every table row; "
                           "use mode='dense' or turn emb_regular off")
         self.dist = dist
+        # dense Adam/AdamW semantics on the touched-rows path: replay a row's skipped zero-gradient steps before it is read
+        self.exact = bool(exact_adam) and mode == "sparse" and self.opt in ("Adam", "AdamW")
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RSError("FusedTrainer: the model must live on the MI355X (there is no CPU path)")
@@ -195,6 +202,39 @@ class FusedTrainer:
         self.hyper = ops.make_hyper(dev, self.lr, eps=eps, weight_decay=wd)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.scal = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
+        self._versions = [(t["tab"], t["tab"].version) for t in self.tables]
+        for t in self.tables:                # an earlier trainer's pending steps, then its counters go
+            t["tab"].flush_rows()
+            t["tab"].row_state = None
+        if self.exact:
+            self._attach_row_state()
+
+    def _attach_row_state(self):
+        """Per-row step counters of the looked-up tables; readers of the tables outside this engine (module forward,
+        evaluate, state_dict) find them on the holder and bring rows up to date before reading."""
+        bctab = None
+        for t in self.tables:
+            if not t["used"]:
+                continue
+            rs = ops.RowAdam(t["w"], t["m"], t["v"], self.opt, self.hyper, self.step_count, bctab=bctab)
+            bctab = rs.bctab
+            t["rs"] = t["tab"].row_state = rs
+
+    def _row_states(self):
+        te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+        return (te or {}).get("rs"), (t1 or {}).get("rs")
+
+    def flush(self):
+        """Bring every table row up to the current step (only the exact Adam mode leaves rows behind)."""
+        for t in self.tables:
+            if t.get("rs") is not None:
+                t["rs"].flush()
+
+    def _check_tables(self):
+        for tab, ver in self._versions:
+            if tab.version != ver:
+                raise RSError("FusedTrainer: the model's tables were moved to other storage after the trainer was "
+                              "built (model.to(another device)?); build a new trainer")
 
     def _table_entry(self, tab):
         for t in self.tables:
@@ -203,6 +243,7 @@ class FusedTrainer:
         return None
 
     def decay_lr(self, factor=0.1, min_lr=1e-6):
+        self.flush()                 # rows left behind are replayed with the rate their skipped steps had
         self.lr = max(self.lr * factor, min_lr)
         self.hyper[0:1].fill_(self.lr)
         return self.lr
@@ -216,13 +257,15 @@ class FusedTrainer:
         return self._plans[B]
 
     # ------------------------------------------------------------------------------------------
-    def forward_parts(self, idx: torch.Tensor, defer_head: bool = False, sort_plan=None):
+    def forward_parts(self, idx: torch.Tensor, defer_head: bool = False, sort_plan=None, mark_ahead: int = 0):
         """Forward pass; returns (logit parts, saved context).  defer_head: leave a 1-wide last block to the
         caller (the training step fuses it with the loss head); then ctx["head_in"] is its input.  sort_plan: also
-        sort the batch into this plan, in the gather's launch."""
+        sort the batch into this plan, in the gather's launch.  mark_ahead=1: this is the forward of a training step
+        (the rows read here are stepped at its end)."""
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
+        self._embed_catch_up(idx, mark_ahead)
         r = self._embed_forward(idx) if sort_plan is None else self._embed_forward_sorting(idx, sort_plan)
         ctx["emb"] = r.get("emb")
         ctx["S"] = r.get("sum")
@@ -262,6 +305,12 @@ class FusedTrainer:
         return parts, ctx
 
     # ---- embedding hooks (overridden by the row-sharded multi-GPU trainer) -----------------------
+    def _embed_catch_up(self, idx, mark_ahead: int):
+        """Exact Adam on touched rows: the rows this batch reads are brought up to the current step first."""
+        if self.exact:
+            main, one = self._row_states()
+            ops.adam_catchup(idx, self.layout, main, one, mark_ahead)
+
     def _embed_forward(self, idx):
         """dict(emb [B,F,d], sum [B,d], lr [B], fm [B]) as needed by the model kind: K1, one launch."""
         table = self.tab.stacked if self.has_emb else None
@@ -340,7 +389,7 @@ class FusedTrainer:
         head_fast = bool(self.blocks) and self._head_fast
         # single GPU, one stream: the sort shares the gather's launch (it keeps only F workgroups busy)
         sort_early = self._fuse_small and not fork_sort
-        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
+        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None, mark_ahead=1)
         lastb = self.blocks[-1] if self.blocks else None
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
         csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None
@@ -545,6 +594,7 @@ class FusedTrainer:
         step).  resident=True promises that these exact tensors stay alive and are re-used (a ring of
         pre-staged batches): one graph is captured per distinct (idx, labels) buffer pair and
         replayed without any copy."""
+        self._check_tables()
         if not self.use_graph:
             with ops.use_workspace(self.ws):
                 return self._step_impl(idx, labels)
@@ -602,6 +652,8 @@ class FusedTrainer:
             for k in ("m", "v"):
                 if t[k] is not None:
                     ts.append(t[k])
+            if t.get("rs") is not None:
+                ts += t["rs"].tensors()
         for b in self.blocks:
             if b.normalization == "bn":
                 ts += [b.norm_layer.running_mean, b.norm_layer.running_var]

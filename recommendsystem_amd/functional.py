@@ -37,6 +37,7 @@ class _GatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, holder, *weights):
         stacked = holder.stacked_for(weights)
+        holder.before_read(idx)
         out = ops.gather_fwd(idx, holder.layout, stacked)
         ctx.holder = holder
         ctx.save_for_backward(idx)
@@ -68,7 +69,7 @@ class TableCapture:
 
     active = None
 
-    def __init__(self, provider=None, grad_sinks=None, splitk=None):
+    def __init__(self, provider=None, grad_sinks=None, splitk=None, on_lookup=None):
         # provider: object with emb(idx, holder) -> [B, F, d] and lr_terms(idx, holder) -> [B, F] (the per-field
         # 1-dim values) that fetches rows from somewhere else than the local stacked table (row-sharded tables)
         # grad_sinks: id(parameter) -> zero-initialised gradient tensor the MLP-block backward writes into directly
@@ -78,6 +79,8 @@ class TableCapture:
         self.provider = provider
         self.grad_sinks = grad_sinks or {}
         self.splitk = splitk
+        # on_lookup(holder, idx): called before a local table is read (the trainer brings the rows up to date)
+        self.on_lookup = on_lookup
         self._sunk = set()
         self._idx = {}           # (id of the batch dict, columns) -> (batch dict, index matrix): one stack per forward
 
@@ -109,6 +112,12 @@ class TableCapture:
         self._sunk.add(pid)
         return t
 
+    def before_lookup(self, holder, idx):
+        if self.on_lookup is not None:
+            self.on_lookup(holder, idx)
+        else:
+            holder.before_read(idx)
+
     def record(self, kind, holder, idx, out):
         out.requires_grad_(True)
         self.records.append({"kind": kind, "holder": holder, "idx": idx, "out": out})
@@ -120,7 +129,9 @@ def embedding_lookup(idx, holder, weights) -> torch.Tensor:
     if cap is not None:
         if cap.provider is not None:
             return cap.record("emb", holder, idx, cap.provider.emb(idx, holder))
-        return cap.record("emb", holder, idx, ops.gather_fwd(idx, holder.layout, holder.stacked_for(weights)))
+        stacked = holder.stacked_for(weights)
+        cap.before_lookup(holder, idx)
+        return cap.record("emb", holder, idx, ops.gather_fwd(idx, holder.layout, stacked))
     return _GatherFn.apply(idx, holder, *weights)
 
 
@@ -130,6 +141,7 @@ class _LRFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, holder, bias, *weights1):
         stacked1 = holder.stacked_for(weights1)
+        holder.before_read(idx)
         out = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias, want_emb=False, want_lr=True)["lr"]
         ctx.holder = holder
         ctx.save_for_backward(idx)
@@ -175,6 +187,7 @@ def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
             raw = ops.rowdot_fwd(terms, ones, bias.detach(), 0)     # sum_f w_f[idx] + bias
         else:
             stacked1 = holder.stacked_for(weights1)
+            cap.before_lookup(holder, idx)
             raw = ops.gather_lr_fm_fwd(idx, holder.layout, None, stacked1, bias.detach(), want_emb=False,
                                        want_lr=True)["lr"]
         return _BiasGradFn.apply(cap.record("lr", holder, idx, raw).view(-1, 1), bias)

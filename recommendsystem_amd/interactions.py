@@ -161,6 +161,7 @@ class _FFMFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, holder, *weights):
         T = holder.stacked_for(weights)
+        holder.before_read(idx)
         ctx.holder = holder
         ctx.save_for_backward(idx, T)
         return ops.ffm_fwd(idx, holder.layout, T).view(-1, 1)
@@ -217,5 +218,6 @@ class FieldAwareTables(nn.Module):
             return out.view(-1, 1)
         if cap is not None:
             T = self._tab.stacked_for(self._tab.weights())
+            cap.before_lookup(self._tab, idx)
             return cap.record("ffm", self._tab, idx, ops.ffm_fwd(idx, self._tab.layout, T)).view(-1, 1)
         return _FFMFn.apply(idx, self._tab, *self._tab.weights())

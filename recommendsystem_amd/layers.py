@@ -32,15 +32,30 @@ class _StackedTables:
         self.stacked = None
         self.layout = None
         self._plans = {}
+        self.version = 0            # bumped whenever `stacked` becomes a different tensor
+        self.row_state = None       # ops.RowAdam of the trainer that steps this table on touched rows only
 
     def weights(self):
         return [self.modules[c].weight for c in self.cols]
 
     def restack(self):
+        """Make every per-column weight a view of one stacked table.  On the device the table already lives on, the
+        existing storage is kept (trainers, their optimizer state and captured HIP graphs hold its address): columns
+        that were given storage of their own are copied back into it.  Only a move to another device allocates."""
         ws = self.weights()
         if not ws:
             return
         dev = ws[0].device
+        st = self.stacked
+        if st is not None and st.device == dev and all(w.device == dev for w in ws):
+            base, esz, o = st.data_ptr(), st.element_size() * self.dim, 0
+            with torch.no_grad():
+                for w, v in zip(ws, self.vocab):
+                    if w.data_ptr() != base + o * esz:
+                        st[o:o + v].copy_(w.data)
+                        w.data = st[o:o + v]
+                    o += v
+            return
         total = sum(self.vocab)
         stacked = torch.empty((total, self.dim), dtype=torch.float32, device=dev)
         o = 0
@@ -49,10 +64,23 @@ class _StackedTables:
                 stacked[o:o + v].copy_(w.data)
                 w.data = stacked[o:o + v]
                 o += v
+        if st is not None:
+            self.version += 1
+            self.row_state = None   # the optimizer state stayed on the old device: its trainer must be rebuilt
         self.stacked = stacked
         if self.layout is None or self.layout.device != dev:
             self.layout = FieldLayout(self.vocab, dev) if dev.type == "cuda" else None
             self._plans = {}
+
+    def before_read(self, idx, mark_ahead: int = 0):
+        """Rows that a touched-rows Adam trainer left behind are brought up to the current step before `idx` reads
+        them (no-op without such a trainer)."""
+        if self.row_state is not None:
+            self.row_state.catch_up(idx, self.layout, mark_ahead)
+
+    def flush_rows(self):
+        if self.row_state is not None:
+            self.row_state.flush()
 
     def stacked_for(self, weights):
         """The stacked table, after checking that the given per-column weights still alias it."""

@@ -694,6 +694,71 @@ def make_hyper(device, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
 
 
 # ---------------------------------------------------------------------------------------------
+# dense Adam semantics on touched-rows tables: replay of the skipped zero-gradient steps
+# ---------------------------------------------------------------------------------------------
+class RowAdam:
+    """What rs_adam_catchup / rs_adam_flush need for ONE stacked table that rs_sparse_update steps on touched rows
+    only: its weights and moments, `last` (int32 per row: optimizer steps already contained in the row) and the
+    trainer's device scalars.  Attached to the table holder as ``holder.row_state`` so that every reader of the
+    table (module forward, evaluate, state_dict) first brings the rows it reads up to date."""
+
+    BC_STEPS = 1 << 16
+
+    def __init__(self, w, m, v, opt: str, hyper, step, beta1: float = 0.9, bctab=None):
+        if opt not in ("Adam", "AdamW"):
+            raise RSError(f"RowAdam: {opt} has no skipped steps to replay")
+        import math
+        self.w, self.m, self.v = w, m, v
+        self.opt, self.hyper, self.step = opt, hyper, step
+        self.rows = w.shape[0]
+        self.d = w.shape[1] if w.dim() == 2 else 1
+        self.last = torch.zeros(self.rows, dtype=torch.int32, device=w.device)
+        # drift terms decay like beta1^j: beyond this many replayed steps they are below 1e-12 of the first one
+        self.kmax = int(math.ceil(math.log(1e-12) / math.log(beta1))) if 0.0 < beta1 < 1.0 else 1
+        self.bctab = bctab if bctab is not None else adam_bc_table(hyper, self.BC_STEPS)
+
+    def catch_up(self, idx: torch.Tensor, layout: FieldLayout, mark_ahead: int = 0):
+        adam_catchup(idx, layout, self if self.d != 1 else None, self if self.d == 1 else None, mark_ahead)
+
+    def flush(self):
+        call("rs_adam_flush", ptr(self.w), ptr(self.m), ptr(self.v), ptr(self.last), self.rows, self.d,
+             OPT_CODES[self.opt], ptr(self.step), ptr(self.hyper), ptr(self.bctab), self.bctab.shape[0], self.kmax,
+             stream())
+
+    def tensors(self):
+        return [self.last]
+
+
+def adam_bc_table(hyper: torch.Tensor, n: int) -> torch.Tensor:
+    """[n, 2] fp32: {1/(1-beta1^k), 1/sqrt(1-beta2^k)} for k < n, evaluated in double precision on the device."""
+    _chk(hyper, torch.float32, "hyper", (8,))
+    tab = torch.empty((n, 2), dtype=torch.float32, device=hyper.device)
+    call("rs_adam_bc_table", ptr(tab), n, ptr(hyper), stream())
+    return tab
+
+
+def adam_catchup(idx: torch.Tensor, layout: FieldLayout, main: Optional[RowAdam], one: Optional[RowAdam],
+                 mark_ahead: int):
+    """Replay the skipped zero-gradient Adam steps of the rows batch `idx` [F, B] is about to read: `main` is the
+    state of the [R, d] table, `one` of the [R] (1-dim) table looked up with the same indices; one launch."""
+    ref = main or one
+    if ref is None:
+        return
+    Fn, B = idx.shape
+    _chk(idx, torch.int64, "idx", (layout.num_fields, B))
+    for st in (main, one):
+        if st is not None and st.rows != layout.total_rows:
+            raise RSError("adam_catchup: table and field layout disagree on the number of rows")
+    if main is not None and one is not None and (main.step is not one.step or main.opt != one.opt):
+        raise RSError("adam_catchup: the two tables belong to different optimizers")
+    g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
+    call("rs_adam_catchup", ptr(idx), ptr(layout.row_offset_t), ptr(layout.vocab_t), B, Fn, main.d if main else 1,
+         g(main, "w"), g(main, "m"), g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"),
+         OPT_CODES[ref.opt], ptr(ref.step), int(mark_ahead), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0],
+         ref.kmax, stream())
+
+
+# ---------------------------------------------------------------------------------------------
 # activation / normalisation kernels
 # ---------------------------------------------------------------------------------------------
 def act_fwd(z: torch.Tensor, act: int, slope=None) -> torch.Tensor:

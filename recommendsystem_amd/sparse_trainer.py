@@ -16,8 +16,12 @@ HIP kernels behind autograd Functions -- while everything that concerns the tabl
 What the reference does instead (and what this replaces): dense (V_f, d) gradients for every table, a norm over all of
 them, and a dense optimizer sweep over every row each step (torch.optim on nn.Embedding weights).
 
-Semantics: identical to the reference's dense optimizers for SGD and Adagrad; Adam/AdamW are the "lazy" variant
-(rows a batch does not touch keep weights and moments).  ``emb_regular`` (a gradient on every row) is not supported.
+Semantics: identical to the reference's dense optimizers for SGD and Adagrad.  Under Adam/AdamW a row that a batch
+does not touch still moves in the reference (zero gradient, decaying moments): with ``exact_adam=True`` (default) each
+table carries a per-row step counter and a row's skipped steps are replayed right before it is next read
+(rs_adam_catchup; ``flush()`` brings every row up to date), which reproduces the dense optimizer;
+``exact_adam=False`` is the "lazy" variant (absent rows keep weights and moments).  ``emb_regular`` (a gradient on
+every row) is not supported.
 
 ``use_graph=True`` replays the whole step, autograd backward included, from a HIP graph (one per batch shape), which
 removes the host cost of the ~60 launches and of the autograd bookkeeping.
@@ -37,7 +41,8 @@ N_DENSE_PARTIALS = 256
 
 
 class SparseTrainer:
-    def __init__(self, model, max_norm: float = 10.0, optimizer_type=None, lr=None, use_graph: bool = False):
+    def __init__(self, model, max_norm: float = 10.0, optimizer_type=None, lr=None, use_graph: bool = False,
+                 exact_adam: bool = True):
         self.model = model
         self.use_graph = bool(use_graph)
         self._graphs = {}
@@ -63,6 +68,8 @@ class SparseTrainer:
         adam = self.opt in ("Adam", "AdamW")
         self.need_m = adam or self.opt == "Adagrad"
         self.need_v = adam
+        self.exact = bool(exact_adam) and adam
+        self._bctab = None
         self.flat_m = torch.zeros_like(self.flat_w) if self.need_m else None
         self.flat_v = torch.zeros_like(self.flat_w) if self.need_v else None
         self.hyper = ops.make_hyper(dev, self.lr, eps=1e-10 if self.opt == "Adagrad" else 1e-8,
@@ -96,18 +103,41 @@ class SparseTrainer:
                 self._gviews.append(self.flat_g[off:off + p.numel()].view_as(p))
 
     def decay_lr(self, factor=0.1, min_lr=1e-6):
+        self.flush()                 # rows left behind are replayed with the rate their skipped steps had
         self.lr = max(self.lr * factor, min_lr)
         self.hyper[0:1].fill_(self.lr)
         return self.lr
 
+    def flush(self):
+        """Bring every table row up to the current step (only the exact Adam mode leaves rows behind)."""
+        for st in self._state.values():
+            if st.get("rs") is not None:
+                st["rs"].flush()
+
     def _table_state(self, holder):
         st = self._state.get(id(holder))
-        if st is None or st["w"] is not holder.stacked:
+        if st is not None and st["w"] is not holder.stacked:
+            raise RSError("SparseTrainer: a table was moved to other storage after training began "
+                          "(model.to(another device)?); build a new trainer")
+        if st is None:
             w = holder.stacked
             st = {"w": w, "m": torch.zeros_like(w) if self.need_m else None,
-                  "v": torch.zeros_like(w) if self.need_v else None}
+                  "v": torch.zeros_like(w) if self.need_v else None, "rs": None}
+            holder.flush_rows()          # an earlier trainer's pending steps, then its counters go
+            holder.row_state = None
+            if self.exact:
+                st["rs"] = holder.row_state = ops.RowAdam(w, st["m"], st["v"], self.opt, self.hyper, self.step_count,
+                                                          bctab=self._bctab)
+                self._bctab = st["rs"].bctab
             self._state[id(holder)] = st
         return st
+
+    def _on_lookup(self, holder, idx):
+        """A captured lookup is about to read `holder`'s table in a training step: replay the skipped steps of the
+        rows it reads and mark them as stepped by this step."""
+        rs = self._table_state(holder)["rs"]
+        if rs is not None:
+            rs.catch_up(idx, holder.layout, 1)
 
     def _plan(self, group, B):
         """One sort plan per group of lookups that share a batch (same index matrix and field vocabularies)."""
@@ -181,6 +211,8 @@ class SparseTrainer:
         ts += list(self.model.buffers())
         for st in self._state.values():
             ts += [st[k] for k in ("m", "v") if st[k] is not None]
+            if st["rs"] is not None:
+                ts += st["rs"].tensors()
         return ts
 
     def _capture(self, idx, labels):
@@ -207,6 +239,8 @@ class SparseTrainer:
                     for name in ("m", "v"):
                         if st[name] is not None:
                             st[name].zero_()
+                    if st["rs"] is not None:
+                        st["rs"].last.zero_()
         restore()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool, stream=side):
@@ -241,7 +275,8 @@ class SparseTrainer:
         direct = not m.net_regular
         sinks = {id(p): gv for p, gv in zip(self.dense, self._gviews)} if direct else None
         splitk = ops.SplitKParts(ops.default_workspace(self.device)) if direct else None
-        with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk) as cap:
+        with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk,
+                             on_lookup=self._on_lookup if self.exact else None) as cap:
             out = m.forward(inputs)
             loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
@@ -253,6 +288,9 @@ class SparseTrainer:
 
     def _step_impl(self, inputs, y) -> torch.Tensor:
         cap, loss = self._forward_backward(inputs, y)
+        if self.exact and any(r["out"].grad is None for r in cap.records):
+            raise RSError("SparseTrainer: a table was looked up but its rows do not reach the loss; with exact Adam "
+                          "every looked-up row must be stepped (drop the lookup or pass exact_adam=False)")
         jobs = []
         n_total = N_DENSE_PARTIALS
         for group in self._groups(cap.records):

@@ -91,9 +91,13 @@ def test_module_path_train_step(fname):
             if p.grad is None:
                 assert key not in g
             else:
-                torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(g[key]), rtol=1e-4, atol=5e-7,
+                # (torch's LayerNorm over the one feature of the last residual block back-propagates rounding noise
+                #  times rstd = 316 instead of an exact zero: the reference's own upstream gradients carry ~2e-4 of it)
+                rtol = 1e-3 if fname == "train_deepcrossing_adam_ln.npz" else 1e-4
+                torch.testing.assert_close(p.grad.cpu(), torch.from_numpy(g[key]), rtol=rtol, atol=5e-7,
                                            msg=lambda s_, n=n: f"{n}: {s_}")
-        compare_state(m, g, f"step{s}.after.", only=lambda name: not noise_driven(fname, name))
+        compare_state(m, g, f"step{s}.after.", only=lambda name: not noise_driven(fname, name),
+                      **(dict(rtol=2e-4, atol=2e-6) if fname == "train_deepcrossing_adam_ln.npz" else {}))
 
 
 @pytest.mark.parametrize("fname", FIXTURES)
@@ -145,12 +149,47 @@ def test_fused_engine_sparse_mode_equals_dense_sgd(fname):
         compare_state(m, g, f"step{s}.after.")
 
 
-def test_fused_engine_sparse_adam_first_step_and_lazy_rows():
-    """Step 1 of Adam from zero state is identical in lazy and dense form; afterwards rows absent from
-    a batch keep their weights in lazy mode while every other parameter still tracks the reference."""
-    g = load_golden("train_deepfm_adam.npz")
+@pytest.mark.parametrize("fname", ["train_deepfm_adam.npz", "train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_engine_sparse_mode_exact_adam(fname, graph):
+    """Touched-rows Adam / AdamW with the skipped zero-gradient steps of a row replayed before it is next read: every
+    step of the reference's traces (up to 12 steps; rows stay absent for several steps in a row while their moments
+    still move them in the reference), logits included.  state_dict() brings all rows up to date before comparing."""
+    g = load_golden(fname)
+    m, feats = build_model(g)
+    eng = m.use_fused_step(mode="sparse", use_graph=graph)
+    assert eng.exact
+    for s in range(int(g["steps"])):
+        x = golden_batch(g, feats, f"step{s}.x.")
+        y = {"label": torch.from_numpy(g[f"step{s}.label"])}
+        idx = m.embedding_layer.index_matrix(m.features_to_divice(x))
+        torch.testing.assert_close(eng.logits(idx).cpu(), torch.from_numpy(g[f"step{s}.logits"]), rtol=1e-5, atol=1e-6)
+        loss = m.train_step(x, y)
+        torch.testing.assert_close(loss.cpu()[0], torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
+        if s % 3 == 2 or s == int(g["steps"]) - 1:          # in between, rows stay behind for several steps
+            compare_state(m, g, f"step{s}.after.", only=lambda n: "embedding_layer.embedded_to_1_dim" not in n
+                          and "lr_layer.scalar.embedded_features" not in n)
+    m.embedding_layer._tab.layout.check_indices()
+
+
+def test_module_forward_reads_caught_up_rows():
+    """A reader outside the engine (the model's own forward) sees the rows the engine left behind brought up to date."""
+    g = load_golden("train_deepfm_adam_long.npz")
     m, feats = build_model(g)
     m.use_fused_step(mode="sparse")
+    for s in range(int(g["steps"])):
+        x = golden_batch(g, feats, f"step{s}.x.")
+        with torch.no_grad():
+            torch.testing.assert_close(m.logits(x).cpu(), torch.from_numpy(g[f"step{s}.logits"]), rtol=1e-5, atol=1e-6)
+        m.train_step(x, {"label": torch.from_numpy(g[f"step{s}.label"])})
+
+
+def test_fused_engine_sparse_adam_first_step_and_lazy_rows():
+    """exact_adam=False: step 1 of Adam from zero state is identical in lazy and dense form; afterwards rows absent
+    from a batch keep their weights in lazy mode while every other parameter still tracks the reference."""
+    g = load_golden("train_deepfm_adam.npz")
+    m, feats = build_model(g)
+    m.use_fused_step(mode="sparse", exact_adam=False)
     x = golden_batch(g, feats, "step0.x.")
     y = {"label": torch.from_numpy(g["step0.label"])}
     m.train_step(x, y)
