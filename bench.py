@@ -3,7 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the environment when N > 1).  A "step" is one
+One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the environment when N > 1; started without them, e.g. as plain
+`python bench.py --gpus 8`, the script starts the N rank processes itself before anything touches a GPU).  A "step" is one
 pass of the whole hot path over one batch of B samples per GPU: fused gather + LR + FM, the MLP
 GEMMs forward and backward, the loss head, the sparse embedding backward, global-norm clipping and
 the optimizer update.  Inputs are resident in HBM before the timed region starts.  Rank 0 prints
@@ -42,6 +43,12 @@ def parse():
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
+    p.add_argument("--exact-adam", type=int, default=1,
+                   help="touched-rows Adam/AdamW with the reference's dense semantics (a row's skipped zero-gradient steps "
+                        "are replayed before it is read); 0 = lazy Adam (absent rows keep weights and moments)")
+    p.add_argument("--launch-check", type=int, default=0,
+                   help="N>1: only prove the launch plumbing (rendezvous over gloo, one all-reduce, rank 0 prints a JSON "
+                        "line); touches no GPU")
     p.add_argument("--tables", type=str, default="sharded", choices=["sharded", "replicated"],
                    help="multi-GPU placement of the embedding tables: row-sharded with an all-to-all exchange, or a "
                         "replica per rank with an all-gather of (row, gradient) pairs")
@@ -141,13 +148,61 @@ def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
                       f"torch CPU ops with {cores} threads ({el:.1f} s)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU, rendezvous on a free
+    local port) and exit with their status.  Runs before anything in this process touches a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:               # a rank died: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
+
+
+def launch_check(rank, world):
+    """Rendezvous and one collective over gloo; no GPU involved."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([1 << rank], dtype=torch.int64)
+    dist.all_reduce(t)
+    ok = int(t.item()) == (1 << world) - 1
+    if rank == 0:
+        print(json.dumps({"launch_check": "ok" if ok else "FAILED", "world": world, "rank_mask": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
     rank = int(os.environ.get("RANK", "0")) if args.gpus > 1 else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) if args.gpus > 1 else 0
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
+    if args.launch_check and world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     rehearse = bool(args.rehearse_on_one_gpu) and world > 1
@@ -177,9 +232,10 @@ def main():
         from recommendsystem_amd.dist import DistributedSparseTrainer
         eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
     elif fused_kind:
-        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=int(args.overlap))
+        eng = model.use_fused_step(mode=args.mode, use_graph=bool(args.graph), overlap=int(args.overlap),
+                                   exact_adam=bool(args.exact_adam))
     else:
-        eng = model.use_sparse_step(use_graph=bool(args.graph))
+        eng = model.use_sparse_step(use_graph=bool(args.graph), exact_adam=bool(args.exact_adam))
 
     nb = max(1, args.distinct_batches)
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
@@ -342,7 +398,11 @@ def main():
                                    + f", embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
                        "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
-                       "embedding_update": args.mode, "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
+                       "embedding_update": args.mode if args.mode == "dense" or args.optimizer not in ("Adam", "AdamW")
+                       else ("sparse, exact: touched rows only, a row's skipped zero-gradient steps replayed before it is read "
+                             "(the reference's dense optimizer)" if getattr(eng, "exact", False)
+                             else "sparse, lazy: absent rows keep weights and moments"),
+                       "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": "single GPU" if world == 1 else (
                            f"dp{world} + replicated tables (RCCL all-gather of (row, gradient) pairs)"

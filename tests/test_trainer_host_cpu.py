@@ -71,3 +71,39 @@ def test_index_matrix_is_built_once_per_forward():
             with Fn.TableCapture():
                 pass
     assert Fn.TableCapture.active is None
+
+
+def test_bench_starts_its_own_ranks_when_run_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment: the script starts the two rank
+    processes itself (before anything touches a GPU), they rendezvous on 127.0.0.1 and rank 0 prints one JSON line.
+    --launch-check stops after the rendezvous and one gloo all-reduce, so this runs without a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launch-check", "1"], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"launch_check": "ok", "world": 2, "rank_mask": 3}
+
+
+def test_bench_rank_failure_ends_the_launch():
+    """A rank that exits with an error takes the launch down with its status instead of leaving the others waiting."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (the ranks are meant to fail)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # without --launch-check the ranks need a GPU, which this container does not have: every rank exits non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0 and "needs an MI355X" in r.stderr
