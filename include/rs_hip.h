@@ -269,16 +269,18 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
 int rs_sparse_bwd_wide_num_partials(int F, int cap);
 int rs_sparse_bwd_reduce_wide(const int* plan, int F, int cap, int W, const float* gout, float* rowgrad, float* chunk_part,
                               float* norm_partials, rs_stream_t stream);
-/* Optimizer step on the touched rows only (hyper: 8 floats, see rs_opt_prepare; scal[1] = clip coefficient). */
+/* Optimizer step on the touched rows only (hyper: 8 floats, see rs_opt_prepare; scal[1] = clip coefficient).
+ * last / last1 (int32 per row of table / table1, or null) with `step`: every stepped row is stamped with *step, the
+ * number of optimizer steps it now contains (see rs_adam_catchup). */
 int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                      float* table, float* m, float* v, float* table1, float* m1, float* v1, const float* hyper,
-                     const float* scal, rs_stream_t stream);
+                     const float* scal, int* last, int* last1, const long long* step, rs_stream_t stream);
 /* rs_sparse_update and rs_dense_update in one launch (optimizer.step() of BaseModel.py:149 over the touched table
  * rows and the flat dense parameter buffer). */
 int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                            float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
                            const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
-                           const float* scal, rs_stream_t stream);
+                           const float* scal, int* last, int* last1, const long long* step, rs_stream_t stream);
 /* Expand row gradients into dense [R,d] / [R] gradients (pre-zeroed by the caller): what nn.Embedding's
  * autograd produces for torch's dense optimizers. */
 int rs_sparse_scatter_dense(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,
@@ -306,9 +308,10 @@ int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* sca
  *   host code computes them; steps beyond tab_n are computed on the fly.  kmax bounds the replay loop (the drift
  *   terms decay like beta1^j; ceil(log(1e-12)/log(beta1)) is enough), the rest is applied in closed form.
  * rs_adam_catchup: for every entry of the columnar batch idx [F,B], bring row row_offset[f]+idx[f,b] of table
- *   (width d) and/or table1 (width 1) up to `*step` steps and mark it as containing *step + mark_ahead steps
- *   (mark_ahead = 1 in a training step, whose rs_sparse_update will apply step *step + 1 to exactly these rows; 0 for
- *   a forward-only pass).  Call it before the lookup.  The learning rate must not have changed since a row's last
+ *   (width d) and/or table1 (width 1) up to `*step` steps and mark it as containing *step + mark_ahead steps.
+ *   Call it before the lookup.  mark_ahead = 0 when the update that follows stamps the rows itself (rs_sparse_update
+ *   with last / last1) and for forward-only passes; 1 when a training step's update cannot stamp (every entry then
+ *   costs an atomic, against a plain load for rows that are up to date).  The learning rate must not have changed since a row's last
  *   step: call rs_adam_flush before changing hyper[0].
  * rs_adam_flush: every row of one table up to *step (before evaluation, state_dict, a learning-rate change). */
 int rs_adam_bc_table(float* bctab, int tab_n, const float* hyper, rs_stream_t stream);

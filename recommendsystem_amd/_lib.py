@@ -47,9 +47,9 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     "rs_sparse_dense_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                               c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_stream],
+                               c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_i32p, c_i32p, c_i64p, c_stream],
     "rs_sparse_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                         c_f32p, c_f32p, c_stream],
+                         c_f32p, c_f32p, c_i32p, c_i32p, c_i64p, c_stream],
     "rs_sparse_scatter_dense": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_dense_update": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
     "rs_sumsq_partials": [c_f32p, L, c_f32p, I, c_stream],

@@ -146,9 +146,11 @@ struct CatchArgs {
 
 constexpr int CT = 256;
 
-// Phase 1: one thread per (field, sample) entry claims its row: atomicMax(last[row], steps + mark_ahead).  Exactly one
-// of the entries that name a stale row sees the old value and becomes its owner, whichever it is the result is the
-// same.  Phase 2: the workgroup replays the rows its threads own, d/VEC lanes per row.
+// Phase 1: one thread per (field, sample) entry looks at its row's stamp; a row that is behind is claimed with
+// atomicMax(last[row], steps + mark_ahead): exactly one of the entries that name it sees the old value and becomes its
+// owner (whichever it is, the result is the same).  Rows that are up to date -- the hot rows of a Zipf batch, stepped
+// and stamped by the previous step's update -- cost one load and no atomic.
+// Phase 2: the workgroup replays the rows its threads own, d/VEC lanes per row.
 template <int VEC>
 __device__ __forceinline__ void catchup_body(const CatchArgs& a, const RowTab& t, int* s_n, int* s_row, int* s_last) {
     if (threadIdx.x == 0) *s_n = 0;
@@ -160,10 +162,13 @@ __device__ __forceinline__ void catchup_body(const CatchArgs& a, const RowTab& t
         const long long key = a.idx[e];
         if (key > 0 && key < a.vocab[f]) {              // row 0 is the padding row: never stepped (Layers.py:132)
             const int row = (int)(a.row_offset[f] + key);
-            const int old = atomicMax(&t.last[row], c + a.mark_ahead);
-            if (old < c) {
-                const int p = atomicAdd(s_n, 1);
-                s_row[p] = row; s_last[p] = old;
+            const int target = c + a.mark_ahead;
+            if (__hip_atomic_load(&t.last[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                const int old = atomicMax(&t.last[row], target);
+                if (old < c) {
+                    const int p = atomicAdd(s_n, 1);
+                    s_row[p] = row; s_last[p] = old;
+                }
             }
         }
     }

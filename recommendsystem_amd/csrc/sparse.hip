@@ -730,6 +730,9 @@ struct UpdateArgs {
     float* table; float* m; float* v;          // [R, d]
     float* table1; float* m1; float* v1;       // [R] (or null)
     const float* hyper; const float* scal;     // device scalars
+    // per-row step stamps of tables whose skipped Adam steps are replayed on touch (rs_adam_catchup): a stepped row
+    // is marked as containing *step optimizer steps (null: no stamps)
+    int* last; int* last1; const long long* step;
 };
 
 template <int VEC>
@@ -753,12 +756,14 @@ __device__ __forceinline__ void sparse_update_body(const UpdateArgs& a, int f, i
         stv<VEC>(a.table + o, w);
         if (a.m) stv<VEC>(a.m + o, mm);
         if (a.v) stv<VEC>(a.v + o, vv);
+        if (cc == 0 && a.last) a.last[row] = (int)*a.step;
     }
     if (cc == 0 && a.table1) {
         float w = a.table1[row];
         opt_update(a.opt, a.hyper, a.rowgrad1[(long long)f * a.cap + u] * coef, w, a.m1 ? a.m1 + row : nullptr,
                    a.v1 ? a.v1 + row : nullptr);
         a.table1[row] = w;
+        if (a.last1) a.last1[row] = (int)*a.step;
     }
 }
 
@@ -1288,8 +1293,10 @@ int rs_sparse_bwd_reduce_wide(const int* plan, int F, int cap, int W, const floa
 // Optimizer step on the touched rows only.  opt: 0 SGD, 1 Adam, 2 AdamW, 3 Adagrad (state in m).
 int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                      float* table, float* m, float* v, float* table1, float* m1, float* v1,
-                     const float* hyper, const float* scal, hipStream_t stream) {
+                     const float* hyper, const float* scal, int* last, int* last1, const long long* step,
+                     hipStream_t stream) {
     RS_CHECK_ARG(plan && hyper, "rs_sparse_update: null argument");
+    RS_CHECK_ARG(!(last || last1) || step, "rs_sparse_update: row stamps need the step counter");
     RS_CHECK_ARG(opt >= 0 && opt <= 3, "rs_sparse_update: unknown optimizer %d", opt);
     RS_CHECK_ARG(!table || rowgrad, "rs_sparse_update: table without rowgrad");
     RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_update: table1 without rowgrad1");
@@ -1301,6 +1308,7 @@ int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const floa
     RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_update: unsupported d=%d", d);
     a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.opt = opt; a.table = table; a.m = m; a.v = v;
     a.table1 = table1; a.m1 = m1; a.v1 = v1; a.hyper = hyper; a.scal = scal;
+    a.last = table ? last : nullptr; a.last1 = table1 ? last1 : nullptr; a.step = step;
     dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
     if (VEC == 4) hipLaunchKernelGGL(sparse_update_kernel<4>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(sparse_update_kernel<1>, grid, block, 0, stream, a);
@@ -1312,8 +1320,9 @@ int rs_sparse_update(const int* plan, int F, int cap, int d, int opt, const floa
 int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                            float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
                            const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
-                           const float* scal, hipStream_t stream) {
+                           const float* scal, int* last, int* last1, const long long* step, hipStream_t stream) {
     RS_CHECK_ARG(plan && hyper && dense_w && dense_g && dense_n >= 0, "rs_sparse_dense_update: null argument");
+    RS_CHECK_ARG(!(last || last1) || step, "rs_sparse_dense_update: row stamps need the step counter");
     RS_CHECK_ARG(opt >= 0 && opt <= 3, "rs_sparse_dense_update: unknown optimizer %d", opt);
     RS_CHECK_ARG(!table || rowgrad, "rs_sparse_dense_update: table without rowgrad");
     RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_dense_update: table1 without rowgrad1");
@@ -1326,6 +1335,7 @@ int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, cons
     RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_dense_update: unsupported d=%d", d);
     a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.opt = opt; a.table = table; a.m = m; a.v = v;
     a.table1 = table1; a.m1 = m1; a.v1 = v1; a.hyper = hyper; a.scal = scal;
+    a.last = table ? last : nullptr; a.last1 = table1 ? last1 : nullptr; a.step = step;
     const int gx = rs_cdiv(cap, 256 / a.C);
     long long db = (dense_n + 255) / 256;
     const int ndb = (int)(db > 2048 ? 2048 : (db < 1 ? 1 : db));

@@ -349,7 +349,8 @@ class FusedTrainer:
         te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
         kw = dict(table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
                   table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
-                  v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None)
+                  v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None,
+                  rs=(te or {}).get("rs"), rs1=(t1 or {}).get("rs"))
         if with_dense:
             plan.update_with_dense(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m, self.flat_v, **kw)
         else:
@@ -389,7 +390,8 @@ class FusedTrainer:
         head_fast = bool(self.blocks) and self._head_fast
         # single GPU, one stream: the sort shares the gather's launch (it keeps only F workgroups busy)
         sort_early = self._fuse_small and not fork_sort
-        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None, mark_ahead=1)
+        # the update at the end of the step stamps the rows it steps, so the catch-up does not mark ahead
+        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
         lastb = self.blocks[-1] if self.blocks else None
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
         csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None

@@ -642,19 +642,26 @@ class SparsePlan:
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(norm_partials), stream())
 
+    @staticmethod
+    def _stamps(rs, rs1):
+        """(last, last1, step) pointers of the tables' RowAdam states: the update stamps every row it steps."""
+        ref = rs or rs1
+        return (ptr(rs.last) if rs is not None else None, ptr(rs1.last) if rs1 is not None else None,
+                ptr(ref.step) if ref is not None else None)
+
     def update_with_dense(self, opt: str, hyper, scal, dense_w, dense_g, dense_m, dense_v, table=None, m=None, v=None,
-                          table1=None, m1=None, v1=None):
-        """Touched-rows step and the flat dense step in one launch."""
+                          table1=None, m1=None, v1=None, rs=None, rs1=None):
+        """Touched-rows step and the flat dense step in one launch.  rs / rs1: RowAdam of table / table1."""
         _chk(dense_w, torch.float32, "dense_w")
         _chk(dense_g, torch.float32, "dense_g", dense_w.shape)
         call("rs_sparse_dense_update", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(table), ptr(m), ptr(v), ptr(table1), ptr(m1), ptr(v1), ptr(dense_w), ptr(dense_g),
-             ptr(dense_m), ptr(dense_v), dense_w.numel(), ptr(hyper), ptr(scal), stream())
+             ptr(dense_m), ptr(dense_v), dense_w.numel(), ptr(hyper), ptr(scal), *self._stamps(rs, rs1), stream())
 
-    def update(self, opt: str, hyper, scal, table=None, m=None, v=None, table1=None, m1=None, v1=None):
+    def update(self, opt: str, hyper, scal, table=None, m=None, v=None, table1=None, m1=None, v1=None, rs=None, rs1=None):
         call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(table), ptr(m), ptr(v), ptr(table1), ptr(m1), ptr(v1), ptr(hyper), ptr(scal),
-             stream())
+             *self._stamps(rs, rs1), stream())
 
     def scatter_dense(self, grad=None, grad1=None):
         call("rs_sparse_scatter_dense", ptr(self.plan), self.F, self.cap, self.d, ptr(self.rowgrad),
@@ -1027,9 +1034,10 @@ class WidePlan(SparsePlan):
         call("rs_sparse_bwd_reduce_wide", ptr(self.plan), self.F, self.cap, self.width, ptr(gout), ptr(self.rowgrad_wide),
              ptr(self.chunk_part_wide), ptr(norm_partials), stream())
 
-    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None):
+    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None, rs=None):
         call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.width, OPT_CODES[opt], ptr(self.rowgrad_wide),
-             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal), stream())
+             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal),
+             *self._stamps(rs, None), stream())
 
 
 def ffm_rows_fwd(G: torch.Tensor, d: int) -> torch.Tensor:
@@ -1082,9 +1090,10 @@ class FFMPlan(SparsePlan):
              ptr(dout), B, self.F, self.cap, self.ffm_d, ptr(self.rowgrad_wide), ptr(self.chunk_part_wide), ptr(norm_partials),
              stream())
 
-    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None):
+    def update_wide(self, opt: str, hyper, scal, T, m=None, v=None, rs=None):
         call("rs_sparse_update", ptr(self.plan), self.F, self.cap, self.width, OPT_CODES[opt], ptr(self.rowgrad_wide),
-             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal), stream())
+             ptr(None), ptr(T), ptr(m), ptr(v), ptr(None), ptr(None), ptr(None), ptr(hyper), ptr(scal),
+             *self._stamps(rs, None), stream())
 
     def scatter_wide(self, dT: torch.Tensor):
         call("rs_sparse_scatter_dense", ptr(self.plan), self.F, self.cap, self.width, ptr(self.rowgrad_wide), ptr(None),

@@ -134,10 +134,10 @@ class SparseTrainer:
 
     def _on_lookup(self, holder, idx):
         """A captured lookup is about to read `holder`'s table in a training step: replay the skipped steps of the
-        rows it reads and mark them as stepped by this step."""
+        rows it reads."""
         rs = self._table_state(holder)["rs"]
         if rs is not None:
-            rs.catch_up(idx, holder.layout, 1)
+            rs.catch_up(idx, holder.layout, 0)        # the update of this step stamps the rows it steps
 
     def _plan(self, group, B):
         """One sort plan per group of lookups that share a batch (same index matrix and field vocabularies)."""
@@ -326,13 +326,14 @@ class SparseTrainer:
         for group, plan, n in jobs:
             st = {k: self._table_state(r["holder"]) for k, r in group.items()}
             if "ffm" in group:
-                plan.update_wide(self.opt, self.hyper, self.scal, st["ffm"]["w"], st["ffm"]["m"], st["ffm"]["v"])
+                plan.update_wide(self.opt, self.hyper, self.scal, st["ffm"]["w"], st["ffm"]["m"], st["ffm"]["v"],
+                                 rs=st["ffm"]["rs"])
             e, l = st.get("emb"), st.get("lr")
             if e is not None or l is not None:
                 flat = lambda t: t.view(-1) if t is not None else None
                 plan.update(self.opt, self.hyper, self.scal,
                             table=e["w"] if e else None, m=e["m"] if e else None, v=e["v"] if e else None,
                             table1=flat(l["w"]) if l else None, m1=flat(l["m"]) if l else None,
-                            v1=flat(l["v"]) if l else None)
+                            v1=flat(l["v"]) if l else None, rs=e["rs"] if e else None, rs1=l["rs"] if l else None)
         self.last = {"records": cap.records, "direct_grads": len(cap._sunk)}
         return loss.detach()
