@@ -319,6 +319,21 @@ int rs_adam_catchup(const int64_t* idx, const int64_t* row_offset, const int64_t
                     float* table, float* m, float* v, int* last, float* table1, float* m1, float* v1, int* last1,
                     int opt, const long long* step, int mark_ahead, const float* hyper, const float* bctab, int tab_n,
                     int kmax, rs_stream_t stream);
+/* rs_adam_catchup for keys that arrive as lists instead of a columnar batch: nlists = nsrc * F lists, list s * F + f of
+ * field f starting at keys[sub_off[l]] with sub_cnt[l] <= per_list keys (the sub-list descriptors of
+ * rs_sparse_bwd_sort / rs_sparse_bwd_merge_lists): the buckets a row-sharded owner receives before it serves them, or
+ * the all-gathered distinct rows of every rank before a replicated table is stepped on their union.  No reference
+ * counterpart (the reference is single-device). */
+int rs_adam_catchup_lists(const int64_t* keys, const int* sub_off, const int* sub_cnt, int nlists, int per_list,
+                          const int64_t* row_offset, const int64_t* vocab, int F, int d, float* table, float* m, float* v,
+                          int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
+                          int mark_ahead, const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
+/* rs_sparse_bwd_sort of a columnar batch and rs_adam_catchup (mark_ahead = 0) of the same batch in one launch: the sort
+ * keeps one workgroup per field busy, the replay runs on the workgroups behind them. */
+int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
+                    const int64_t* vocab, const int64_t* row_offset, int* plan, int B, int F, int d, float* table, float* m,
+                    float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
+                    const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
 int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, int d, int opt, const long long* step,
                   const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
 

@@ -60,6 +60,10 @@ _SIGS = {
     "rs_adam_bc_table": [c_f32p, I, c_f32p, c_stream],
     "rs_adam_catchup": [c_i64p, c_i64p, c_i64p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p,
                         I, c_i64p, I, c_f32p, c_f32p, I, I, c_stream],
+    "rs_adam_catchup_lists": [c_i64p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p,
+                              c_f32p, c_i32p, I, c_i64p, I, c_f32p, c_f32p, I, I, c_stream],
+    "rs_sort_catchup": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p,
+                        c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
     "rs_adam_flush": [c_f32p, c_f32p, c_f32p, c_i32p, L, I, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
     # elementwise.hip
     "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F,

@@ -162,6 +162,11 @@ class BaseModel(nn.Module):
         eng = self._engine
         if eng is not None and hasattr(eng, "flush"):
             eng.flush()
+        for mod in self.modules():              # trainers built directly on the model leave their stamps on the holders
+            for name in ("_tab", "_tab1"):
+                holder = getattr(mod, name, None)
+                if holder is not None and hasattr(holder, "flush_rows"):
+                    holder.flush_rows()
 
     def state_dict(self, *args, **kwargs):
         self._flush_engine()

@@ -18,6 +18,7 @@
 //      scatter_rowgrad      alternative consumer: expand into a dense (R, d) gradient for callers
 //                           that keep the reference's dense torch optimizers.
 #include "common.h"
+#include "rowstate_body.h"
 #include "colsum_finish.h"
 #include "gather_body.h"
 #include "splitk_multi.h"
@@ -448,6 +449,28 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(SortArgs a, G
         return;
     }
     gather_fused_body<VEC>(ga, ((int)blockIdx.x - a.F) * (SORT_THREADS / 64) + (threadIdx.x >> 6));
+}
+
+// The index sort beside the catch-up of the rows the batch is about to read (rowstate_body.h): both need only the
+// batch, the sort keeps F workgroups busy and the replay of skipped Adam steps runs on the workgroups behind them.
+template <int ITEMS>
+__global__ __launch_bounds__(SORT_THREADS) void sort_catchup_kernel(SortArgs a, CatchArgs ca, int per_table) {
+    if ((int)blockIdx.x < a.F) {
+        field_sort_body<ITEMS>(a, blockIdx.x);
+        return;
+    }
+    catchup_block<SORT_THREADS>(ca, (int)blockIdx.x - a.F, per_table);
+}
+
+template <int IT>
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_catchup_kernel(SortArgs a, int tiles, unsigned long long* tiles64,
+                                                                         CatchArgs ca, int per_table) {
+    const int nsort = a.F * tiles;
+    if ((int)blockIdx.x < nsort) {
+        tile_sort_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles64);
+        return;
+    }
+    catchup_block<SORT_THREADS>(ca, (int)blockIdx.x - nsort, per_table);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1147,6 +1170,67 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
     }
 #undef RS_SG_LAUNCH
     RS_CHECK_LAUNCH("rs_sort_gather");
+    return RS_OK;
+}
+
+// rs_sparse_bwd_sort of a columnar batch with rs_adam_catchup (mark_ahead = 0) of the same batch in one launch.
+int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
+                    const int64_t* vocab, const int64_t* row_offset, int* plan, int B, int F, int d, float* table, float* m,
+                    float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
+                    const float* hyper, const float* bctab, int tab_n, int kmax, hipStream_t stream) {
+    RS_CHECK_ARG(idx && sub_off && sub_cnt && pay_base && vocab && row_offset && plan && step && hyper,
+                 "rs_sort_catchup: null argument");
+    RS_CHECK_ARG(B > 0 && F > 0 && L > 0 && cap >= B, "rs_sort_catchup: bad sizes");
+    RS_CHECK_ARG(B <= SORT_THREADS * 16, "rs_sort_catchup: %d entries per field exceed the in-LDS sort limit %d", B,
+                 SORT_THREADS * 16);
+    RS_CHECK_ARG(opt == RS_OPT_ADAM || opt == RS_OPT_ADAMW, "rs_sort_catchup: optimizer %d has nothing to replay", opt);
+    RS_CHECK_ARG(kmax >= 0 && tab_n >= 0 && (tab_n == 0 || bctab), "rs_sort_catchup: bad replay table");
+    SortArgs a;
+    a.keys = idx; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = F;
+    a.nsrc = 1; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
+    const PlanView pv = carve_plan(plan, F, cap);
+    a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.entry_seg = pv.entry_seg;
+    a.chunk_start = pv.chunk_start; a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk;
+    a.counts = pv.counts;
+    CatchArgs ca{};
+    const int nt = fill_catchup(ca, idx, row_offset, vocab, B, F, d, table, m, v, last, table1, m1, v1, last1, opt, step, 0,
+                                hyper, bctab, tab_n, kmax);
+    RS_CHECK_ARG(nt > 0, "rs_sort_catchup: no table, or a table without m / v / last, or a row width the kernels do not take (%d)", d);
+    const int per_table = rs_cdiv((long long)B * F, SORT_THREADS);
+    const int cblocks = per_table * nt;
+    TwoLevelShape sh;
+    if (two_level_shape(B, 1, &sh)) {
+        unsigned long long* tiles64 = plan_tiles(plan, F, cap);
+        const size_t tsm = sort_lds(sh.it);
+        const dim3 grid(F * sh.tiles + cblocks), block(SORT_THREADS);
+#define RS_TSC_LAUNCH(IT) hipLaunchKernelGGL((tile_sort_catchup_kernel<IT>), grid, block, tsm, stream, a, sh.tiles, tiles64, ca, per_table)
+        if (sh.it == 1) RS_TSC_LAUNCH(1); else if (sh.it == 2) RS_TSC_LAUNCH(2); else RS_TSC_LAUNCH(4);
+#undef RS_TSC_LAUNCH
+        const int rc = launch_rank_tail(a, sh, tiles64, stream);
+        if (rc != RS_OK) return rc;
+        RS_CHECK_LAUNCH("rs_sort_catchup");
+        return RS_OK;
+    }
+    int items = 1;
+    while (items * SORT_THREADS < B) items <<= 1;
+    const size_t smem = sort_lds(items);
+#define RS_SC_LAUNCH(IT)                                                                            \
+    do {                                                                                            \
+        static bool attr = false;                                                                   \
+        if (!attr) {                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_catchup_kernel<IT>),         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
+                rs_set_error("rs_sort_catchup: cannot reserve %zu bytes of LDS", smem);             \
+                return RS_ERR_LAUNCH;                                                               \
+            }                                                                                       \
+            attr = true;                                                                            \
+        }                                                                                           \
+        hipLaunchKernelGGL((sort_catchup_kernel<IT>), dim3(F + cblocks), dim3(SORT_THREADS), smem, stream, a, ca, per_table); \
+    } while (0)
+    if (items == 1) RS_SC_LAUNCH(1); else if (items == 2) RS_SC_LAUNCH(2); else if (items == 4) RS_SC_LAUNCH(4);
+    else if (items == 8) RS_SC_LAUNCH(8); else RS_SC_LAUNCH(16);
+#undef RS_SC_LAUNCH
+    RS_CHECK_LAUNCH("rs_sort_catchup");
     return RS_OK;
 }
 

@@ -222,6 +222,12 @@ class HipShardKernels:
              self.spec.N, self.F, self.cap_b, self.d, ptr(table), ptr(table1), ptr(rows), ptr(rows1),
              ptr(self.layout_own.err_flag), stream())
 
+    def catch_up(self, recv_idx, rs, rs1):
+        """Owner, exact Adam on touched rows: the rows the received buckets name are brought up to the current step
+        before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard)."""
+        call("rs_shard_counts", ptr(recv_idx), self.spec.N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
+        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.cap_b, self.layout_own, rs, rs1)
+
     def expand(self, route, rows, rows1, emb, lr1):
         call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d, ptr(rows),
              ptr(rows1), ptr(emb), ptr(lr1), stream())
@@ -247,12 +253,13 @@ class HipShardKernels:
         self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
                              g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
 
-    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, dense=None):
+    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, dense=None, rs=None, rs1=None):
         """Touched-rows step on the shard; dense = (w, g, m, v): the flat dense step in the same launch."""
         if dense is not None:
-            self.plan_own.update_with_dense(opt, hyper, scal, *dense, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
+            self.plan_own.update_with_dense(opt, hyper, scal, *dense, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1,
+                                            rs=rs, rs1=rs1)
         else:
-            self.plan_own.update(opt, hyper, scal, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1)
+            self.plan_own.update(opt, hyper, scal, table=table, m=m, v=v, table1=table1, m1=m1, v1=v1, rs=rs, rs1=rs1)
 
     @property
     def n_own_partials(self):
@@ -293,8 +300,8 @@ class HipShardKernelsWide(HipShardKernels):
                                   max_entries=N * self.cap_b)
         self.plan_own.reduce_wide(partials, grads.view(-1, self.d))
 
-    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1):
-        self.plan_own.update_wide(opt, hyper, scal, table, m, v)
+    def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, rs=None, rs1=None):
+        self.plan_own.update_wide(opt, hyper, scal, table, m, v, rs=rs)
 
     @property
     def n_own_partials(self):
@@ -327,12 +334,15 @@ class ShardedExchange:
         self.g1_s = z((N, F, cap_b)) if with_lr else None
         self.g1_r = z((N, F, cap_b)) if with_lr else None
 
-    def forward(self, idx, table, table1, emb_out, lr1_out):
-        """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values."""
+    def forward(self, idx, table, table1, emb_out, lr1_out, rs=None, rs1=None):
+        """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values.  rs / rs1: ops.RowAdam of
+        table / table1 when the owner replays skipped Adam steps of the requested rows before serving them."""
         k, c = self.k, self.comm
         k.sort_batch(idx)
         k.route(self.send_idx, self.route, self.overflow)
         c.all_to_all(self.recv_idx, self.send_idx)
+        if rs is not None or rs1 is not None:
+            k.catch_up(self.recv_idx, rs, rs1)
         k.gather(self.recv_idx, table, table1, self.rows_s, self.rows1_s)
         if self.with_emb:
             c.all_to_all(self.rows_r, self.rows_s)
@@ -380,7 +390,6 @@ class DistributedTrainer(FusedTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
-        kw.setdefault("exact_adam", False)
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
@@ -399,6 +408,14 @@ class DistributedTrainer(FusedTrainer):
         self.shard1_v = zl(self.shard1) if (self.has_lr and adam) else None
         for t in self.tables:            # the replicated full tables carry no optimizer state here
             t["m"] = t["v"] = None
+        # exact Adam on touched rows: the per-row step stamps live with the shards, on their owner
+        self.rs_shard = self.rs_shard1 = None
+        if self.exact:
+            if self.has_emb:
+                self.rs_shard = ops.RowAdam(self.shard, self.shard_m, self.shard_v, self.opt, self.hyper, self.step_count)
+            if self.has_lr:
+                self.rs_shard1 = ops.RowAdam(self.shard1, self.shard1_m, self.shard1_v, self.opt, self.hyper, self.step_count,
+                                             bctab=self.rs_shard.bctab if self.rs_shard is not None else None)
         self._ex = {}
         self.ones_F = torch.ones(self.F, dtype=torch.float32, device=self.device)
         # the dense tower must start identical on every rank
@@ -418,6 +435,17 @@ class DistributedTrainer(FusedTrainer):
     def _grad_scale(self) -> float:
         return 1.0 / self.world          # mean over the N*B samples of the global batch
 
+    def _attach_row_state(self):
+        """The model's full tables are not trained here (the shards are): they carry no step stamps."""
+
+    def _embed_catch_up(self, idx, mark_ahead: int):
+        """The owners replay skipped steps inside the exchange, once they know which rows are requested."""
+
+    def flush(self):
+        for rs in (self.rs_shard, self.rs_shard1):
+            if rs is not None:
+                rs.flush()
+
     def _embed_forward(self, idx):
         B = idx.shape[1]
         ex = self.exchange(B)
@@ -425,7 +453,7 @@ class DistributedTrainer(FusedTrainer):
         emb = torch.empty((B, self.F, self.d), dtype=torch.float32, device=dev) if self.has_emb else None
         lr1 = torch.empty((B, self.F), dtype=torch.float32, device=dev) if self.has_lr else None
         ex.forward(idx, self.shard, self.shard1, emb.view(B * self.F, self.d) if emb is not None else None,
-                   lr1.view(-1) if lr1 is not None else None)
+                   lr1.view(-1) if lr1 is not None else None, rs=self.rs_shard, rs1=self.rs_shard1)
         r = {"emb": emb}
         if self.has_fm:
             r.update(ops.fm_fwd(emb, want_sum=True, want_fm=True))
@@ -456,7 +484,8 @@ class DistributedTrainer(FusedTrainer):
         ex = self._ex[plan.cap]
         ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
                     self.shard1_m, self.shard1_v,
-                    dense=(self.flat_w, self.flat_g, self.flat_m, self.flat_v) if with_dense else None)
+                    dense=(self.flat_w, self.flat_g, self.flat_m, self.flat_v) if with_dense else None,
+                    rs=self.rs_shard, rs1=self.rs_shard1)
 
     # ---- HIP-graph segments between the collectives --------------------------------------------------
     def _capture(self, idx, labels):
@@ -508,11 +537,15 @@ class DistributedTrainer(FusedTrainer):
         for x in (self.shard, self.shard1, self.shard_m, self.shard_v, self.shard1_m, self.shard1_v):
             if x is not None:
                 ts.append(x)
+        for rs in (self.rs_shard, self.rs_shard1):
+            if rs is not None:
+                ts += rs.tensors()
         return ts
 
     # ---- utilities ---------------------------------------------------------------------------------
     def sync_to_model(self):
         """All-gather the shards into the model's (replicated) embedding parameters."""
+        self.flush()
         if self.has_emb:
             self.spec.unshard_into(self.tab.stacked, self._gather_shards(self.shard))
         if self.has_lr:
@@ -614,7 +647,6 @@ class ReplicatedTablesTrainer(FusedTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         kw.pop("mode", None)
-        kw.setdefault("exact_adam", False)
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
         self._sort_can_fork = False
         self._update_shares_launch = True
@@ -642,6 +674,9 @@ class ReplicatedTablesTrainer(FusedTrainer):
         rx = self._replica(B)
         rx.merge(plan.seg_rows(), plan.counts()[:, 2], plan.rowgrad if self.has_emb else None,
                  plan.rowgrad1 if self.has_lr else None)
+        if self.exact:
+            # the update steps the union of every rank's rows: the ones only other ranks read are brought up to date here
+            ops.adam_catchup_lists(rx.keys_all.view(-1), rx.k.sub_off, rx.cnt_all.view(-1), B, self.layout, *self._row_states())
         P = plan.partials
         P[:plan.n_partials].zero_()
         ops.colsum(rx.partials.view(-1, 1), out=P[0:1])
@@ -655,7 +690,8 @@ class ReplicatedTablesTrainer(FusedTrainer):
     _capture = DistributedTrainer._capture
 
     def sync_to_model(self):
-        """Nothing to gather: the model's tables are this rank's replica."""
+        """Nothing to gather: the model's tables are this rank's replica (rows left behind are brought up to date)."""
+        self.flush()
 
     def check(self):
         self.layout.check_indices()
@@ -674,21 +710,21 @@ class _ShardedLookups:
         st, ex = self.t._sharded(holder, "emb", idx.shape[1])
         F, B = idx.shape
         out = torch.empty((B, F, holder.dim), dtype=torch.float32, device=idx.device)
-        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None)
+        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None, rs=st["rs"])
         return out
 
     def ffm_rows(self, idx, holder):
         st, ex = self.t._sharded(holder, "ffm", idx.shape[1])
         F, B = idx.shape
         out = torch.empty((B, F, holder.dim), dtype=torch.float32, device=idx.device)
-        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None)
+        ex.forward(idx, st["shard"], None, out.view(B * F, holder.dim), None, rs=st["rs"])
         return out
 
     def lr_terms(self, idx, holder):
         st, ex = self.t._sharded(holder, "lr", idx.shape[1])
         F, B = idx.shape
         out = torch.empty((B, F), dtype=torch.float32, device=idx.device)
-        ex.forward(idx, None, st["shard"], None, out.view(-1))
+        ex.forward(idx, None, st["shard"], None, out.view(-1), rs1=st["rs"])
         return out
 
 
@@ -706,7 +742,6 @@ class DistributedSparseTrainer(SparseTrainer):
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
-        kw.setdefault("exact_adam", False)
         super().__init__(model, **kw)
         self._shards = {}
         self._provider = _ShardedLookups(self)
@@ -721,7 +756,10 @@ class DistributedSparseTrainer(SparseTrainer):
                 shard = shard.view(-1)
             st = {"holder": holder, "kind": kind, "spec": spec, "shard": shard,
                   "m": torch.zeros_like(shard) if self.need_m else None,
-                  "v": torch.zeros_like(shard) if self.need_v else None, "ex": {}}
+                  "v": torch.zeros_like(shard) if self.need_v else None, "ex": {}, "rs": None}
+            if self.exact:      # per-row step stamps of the shard, on its owner
+                st["rs"] = ops.RowAdam(shard, st["m"], st["v"], self.opt, self.hyper, self.step_count, bctab=self._bctab)
+                self._bctab = st["rs"].bctab
             self._shards[id(holder)] = st
         ex = st["ex"].get(B)
         if ex is None:
@@ -772,14 +810,20 @@ class DistributedSparseTrainer(SparseTrainer):
         ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
         for st, ex in jobs:
             if st["kind"] != "lr":
-                ex.k.update(self.opt, self.hyper, self.scal, st["shard"], st["m"], st["v"], None, None, None)
+                ex.k.update(self.opt, self.hyper, self.scal, st["shard"], st["m"], st["v"], None, None, None, rs=st["rs"])
             else:
-                ex.k.update(self.opt, self.hyper, self.scal, None, None, None, st["shard"], st["m"], st["v"])
+                ex.k.update(self.opt, self.hyper, self.scal, None, None, None, st["shard"], st["m"], st["v"], rs1=st["rs"])
         self.last = {"records": cap.records, "direct_grads": len(cap._sunk)}
         return loss.detach()
 
+    def flush(self):
+        for st in self._shards.values():
+            if st["rs"] is not None:
+                st["rs"].flush()
+
     def sync_to_model(self):
         """All-gather the shards into the model's (replicated) table parameters."""
+        self.flush()
         for st in self._shards.values():
             shard = st["shard"].view(-1, 1) if st["kind"] == "lr" else st["shard"]
             n = torch.tensor([shard.shape[0]], dtype=torch.int64, device=shard.device)

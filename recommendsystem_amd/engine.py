@@ -265,8 +265,13 @@ class FusedTrainer:
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
-        self._embed_catch_up(idx, mark_ahead)
-        r = self._embed_forward(idx) if sort_plan is None else self._embed_forward_sorting(idx, sort_plan)
+        if self.exact and sort_plan is not None and mark_ahead == 0:
+            # the replay of skipped Adam steps must precede the lookup: it shares the sort's launch, the gather follows
+            sort_plan.sort_and_catchup(idx, *self._row_states())
+            r = self._embed_forward(idx)
+        else:
+            self._embed_catch_up(idx, mark_ahead)
+            r = self._embed_forward(idx) if sort_plan is None else self._embed_forward_sorting(idx, sort_plan)
         ctx["emb"] = r.get("emb")
         ctx["S"] = r.get("sum")
         if self.has_lr:

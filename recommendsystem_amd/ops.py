@@ -600,6 +600,26 @@ class SparsePlan:
              stream())
         return out
 
+    def sort_and_catchup(self, idx: torch.Tensor, main, one):
+        """sort_columnar(idx) and adam_catchup(idx, layout, main, one, mark_ahead=0) in one launch (main / one: the
+        RowAdam states of the [R, d] and the 1-dim table looked up with idx; the update that follows stamps the rows)."""
+        Fn, B = idx.shape
+        _chk(idx, torch.int64, "idx", (self.F, B))
+        if B > self.cap:
+            raise RSError(f"sparse backward: batch {B} exceeds plan capacity {self.cap}")
+        ref = main or one
+        for st in (main, one):
+            if st is not None and st.rows != self.layout.total_rows:
+                raise RSError("sort_and_catchup: table and field layout disagree on the number of rows")
+        if main is not None and one is not None and (main.step is not one.step or main.opt != one.opt):
+            raise RSError("sort_and_catchup: the two tables belong to different optimizers")
+        g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
+        off, cnt, base = self.columnar_lists(B)
+        call("rs_sort_catchup", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK, ptr(self.layout.vocab_t),
+             ptr(self.layout.row_offset_t), ptr(self.plan), B, Fn, main.d if main else 1, g(main, "w"), g(main, "m"),
+             g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt],
+             ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, stream())
+
     def sort_lists(self, keys, sub_off, sub_cnt, pay_base, nsrc: int, max_entries: int):
         """General form: per field, `nsrc` packed sub-lists of keys; gradient rows are packed likewise."""
         _chk(keys, torch.int64, "keys")
@@ -734,6 +754,26 @@ class RowAdam:
 
     def tensors(self):
         return [self.last]
+
+
+def adam_catchup_lists(keys: torch.Tensor, sub_off: torch.Tensor, sub_cnt: torch.Tensor, per_list: int, layout: FieldLayout,
+                       main: Optional["RowAdam"], one: Optional["RowAdam"], mark_ahead: int = 0):
+    """adam_catchup for keys that arrive as nsrc * F lists (list s * F + f of field f: keys[sub_off[l] : + sub_cnt[l]])."""
+    ref = main or one
+    if ref is None:
+        return
+    _chk(keys, torch.int64, "keys")
+    nlists = sub_off.numel()
+    _chk(sub_off, torch.int32, "sub_off", (nlists,))
+    _chk(sub_cnt, torch.int32, "sub_cnt", (nlists,))
+    for st in (main, one):
+        if st is not None and st.rows != layout.total_rows:
+            raise RSError("adam_catchup_lists: table and field layout disagree on the number of rows")
+    g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
+    call("rs_adam_catchup_lists", ptr(keys), ptr(sub_off), ptr(sub_cnt), nlists, int(per_list), ptr(layout.row_offset_t),
+         ptr(layout.vocab_t), layout.num_fields, main.d if main else 1, g(main, "w"), g(main, "m"), g(main, "v"),
+         g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt], ptr(ref.step),
+         int(mark_ahead), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, stream())
 
 
 def adam_bc_table(hyper: torch.Tensor, n: int) -> torch.Tensor:
