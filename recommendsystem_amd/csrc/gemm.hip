@@ -25,6 +25,7 @@
 #include "colsum_finish.h"
 #include "splitk_multi.h"
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -990,6 +991,60 @@ int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, floa
     else hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, stream, X, M, N, ld, scale, workspace);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 64)), dim3(256), 0, stream, workspace, chunks, N, out);
     RS_CHECK_LAUNCH("rs_colsum_f32");
+    return RS_OK;
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------
+// rs_colsum_f32 for callers that cannot provide (or allocate) a workspace: the stage-1 partial sums go to a device
+// array that belongs to the library.  Each GPU holds its own copy of the array at its own address; the address is
+// looked up once per device, with that device current, and kept.
+constexpr size_t NOALLOC_SCRATCH_FLOATS = (size_t)1 << 20;          // 4 MiB per GPU
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[NOALLOC_SCRATCH_FLOATS];
+static std::atomic<float*> g_scratch_ptr[NOALLOC_MAX_DEVICES];
+
+// device address of `scratch` on the current device (null + error message on failure)
+static float* noalloc_scratch() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        rs_set_error("rs_colsum_f32_noalloc: cannot identify the current device (%d)", dev);
+        return nullptr;
+    }
+    float* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p) return p;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+        rs_set_error("rs_colsum_f32_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        return nullptr;
+    }
+    g_scratch_ptr[dev].store(p, std::memory_order_release);
+    return p;
+}
+
+size_t rs_colsum_noalloc_max_floats(void) { return NOALLOC_SCRATCH_FLOATS; }
+
+int rs_colsum_f32_noalloc(const float* X, int M, int N, int ld, const float* scale, float* out, hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "rs_colsum_f32_noalloc: bad sizes");
+    if (N == 0) return RS_OK;
+    RS_CHECK_ARG(out, "rs_colsum_f32_noalloc: null output");
+    if (M == 0) {
+        if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream) != hipSuccess) return RS_ERR_LAUNCH;
+        return RS_OK;
+    }
+    RS_CHECK_ARG(X, "rs_colsum_f32_noalloc: null input");
+    const int chunks = rs_cdiv(M, CS_ROWS);
+    RS_CHECK_ARG((size_t)chunks * (size_t)N <= NOALLOC_SCRATCH_FLOATS,
+                 "rs_colsum_f32_noalloc: ceil(M/%d) * N = %zu partial sums exceed the library's %zu-float scratch array; "
+                 "use rs_colsum_f32 with a workspace of your own", CS_ROWS, (size_t)chunks * (size_t)N, NOALLOC_SCRATCH_FLOATS);
+    float* ws = noalloc_scratch();
+    if (!ws) return RS_ERR_LAUNCH;
+    // stage 1 writes every partial sum stage 2 reads, so nothing of the previous call's contents has to be cleared
+    const bool vec = aligned16(X) && ld % 4 == 0 && N % 4 == 0;
+    dim3 grid(rs_cdiv(N, 256), chunks);
+    if (vec) hipLaunchKernelGGL(colsum_stage1_kernel<true>, grid, dim3(256), 0, stream, X, M, N, ld, scale, ws);
+    else hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, stream, X, M, N, ld, scale, ws);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(rs_cdiv(N, 64)), dim3(256), 0, stream, ws, chunks, N, out);
+    RS_CHECK_LAUNCH("rs_colsum_f32_noalloc");
     return RS_OK;
 }
 
