@@ -42,6 +42,8 @@ def parse():
                    help="39 = 13 small-vocabulary + 26 categorical fields; 26 = the categorical fields only")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
+    p.add_argument("--activation", type=str, default="ReLU",
+                   help="activation of the MLP blocks (the reference's default ReLU also sits on the 1-wide last block)")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
     p.add_argument("--exact-adam", type=int, default=1,
                    help="touched-rows Adam/AdamW with the reference's dense semantics (a row's skipped zero-gradient steps "
@@ -87,6 +89,8 @@ def build(args, device):
     hidden = [int(h) for h in args.hidden.split(",") if h]
     gpu = device.index
     kw = dict(optimizer_type=args.optimizer)
+    if args.model in ("deepfm", "dnn", "widedeep", "pnn", "pnn_inner", "dcn", "nfm"):
+        kw["activation_func"] = args.activation
     if args.model == "deepfm":
         m = models.DeepFM(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
     elif args.model == "fm":
@@ -123,6 +127,8 @@ def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
         args.model, {"hidden": hidden, "normalization": None})
     if args.model in ("pnn", "pnn_inner"):
         okw.update(hidden=hidden, normalization=None)
+    if "hidden" in okw:
+        okw["activation"] = args.activation
     m = O.OracleCTRModel(args.model.split("_")[0], rec.feature_map, rec.features, args.dim, **okw)
     m.train()
     opt = O.make_optimizer(args.optimizer, m.parameters(), 1e-3)
@@ -327,20 +333,35 @@ def main():
             lay["launches"] += a["n"]
             lay["total_us"] += a["total_us"]
         elif a["unit"] == "byte":
+            # a launch of ~10 us: the ~4 us an empty event pair reports is a large share of it, so the figure with the
+            # raw event duration (an upper bound of the kernel's own time) is the one quoted; both are printed
+            ent["avg_us_raw"] = round(a["raw_avg_us"], 2)
             ent["gbs"] = round(a["work"] / a["avg_us"] / 1e3, 1)
             ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e3 / HBM_PEAK_GBS, 4)
+            ent["gbs_raw"] = round(a["work"] / a["raw_avg_us"] / 1e3, 1)
+            ent["frac_of_peak_raw"] = round(a["work"] / a["raw_avg_us"] / 1e3 / HBM_PEAK_GBS, 4)
             gather = (a, ent)
         kernels.append(ent)
     for lay in by_layout.values():
         lay["avg_us"] = round(lay["total_us"] / max(lay["launches"], 1), 2)
         lay["total_us"] = round(lay["total_us"], 1)
-    traffic = None
-    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tp):
+    # HBM-side bytes per launch of a kernel family from the committed counter passes (profiles/pmc_traffic.json:
+    # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this benchmark's default configuration); null for any other
+    # configuration, whose traffic those passes did not measure
+    def pmc_traffic(prefix):
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        default_cfg = (args.model == "deepfm" and args.batch == 4096 and args.fields == 39 and args.dim == 16
+                       and args.hidden == "1024,512,256" and not args.uniform)
+        if not (os.path.exists(tp) and default_cfg):
+            return None
         try:
-            traffic = json.load(open(tp)).get("dominant_kernel_hbm_bytes_per_launch")
+            ks = [v for k, v in json.load(open(tp))["kernels"].items() if k.startswith(prefix)]
+            n = sum(v["launches"] for v in ks)
+            return sum(v["launches"] * (v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) for v in ks) / n if n else None
         except Exception:
-            traffic = None
+            return None
+    traffic = pmc_traffic("gemm_f32_dma_kernel")
+    gather_traffic = pmc_traffic("gather_fused_kernel")
     roofline = None
     if gemm_us > 0:
         ach = gemm_flop / gemm_us / 1e6
@@ -353,20 +374,24 @@ def main():
                     "event_pair_overhead_us_subtracted": round(timer.overhead_us, 2)}
     elif gather is not None:
         a, ent = gather
-        roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ent["frac_of_peak"], "traffic": traffic, "measured_in": measured_in}
+        roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs_raw"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ent["frac_of_peak_raw"], "traffic": gather_traffic, "measured_in": measured_in}
     roofline_hbm = None
     if gather is not None:
         a, ent = gather
-        roofline_hbm = {"bound": "hbm", "kernel": "gather_fused_kernel (K1)", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ent["frac_of_peak"], "algorithmic_bytes_per_launch": a["work"],
-                        "avg_us": ent["avg_us"]}
+        roofline_hbm = {"bound": "hbm", "kernel": "gather_fused_kernel (K1)", "achieved": ent["gbs_raw"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ent["frac_of_peak_raw"], "algorithmic_bytes_per_launch": a["work"],
+                        "avg_us": ent["avg_us_raw"], "traffic": gather_traffic,
+                        "note": "duration = raw HIP-event pair (includes the pair's own ~4 us); with that overhead "
+                                f"subtracted: {ent['avg_us']} us, frac {ent['frac_of_peak']}; the rocprofv3 average of this "
+                                "kernel is in profiles/*_bench_kernel_stats.csv"}
 
     # K3 (sparse backward + touched-rows update) against the HBM roofline: algorithmic bytes = per entry the index and
     # the gradient row (+ the embedding row re-read where the FM term is formed on the fly), per distinct row the
     # optimizer's reads and writes of w (and its moments), over the separately timed sort + reduce + update launches.
     roofline_hbm_scatter = None
-    k3_us = sum(per_step.get(k, 0.0) for k in ("rs_sparse_bwd_sort", "rs_sparse_bwd_reduce", "rs_sparse_update"))
+    k3_us = sum(per_step.get(k, 0.0) for k in ("rs_sparse_bwd_sort", "rs_sparse_bwd_reduce", "rs_sparse_update",
+                                               "rs_adam_catchup"))
     if not use_dist and fused_kind and args.mode == "sparse" and k3_us > 0 and hasattr(eng, "plan"):
         plan = eng.plan(args.batch)
         uniq = int(plan.counts()[:, 2].sum().item())             # distinct non-padding rows of the last batch
@@ -378,7 +403,9 @@ def main():
         roofline_hbm_scatter = {"bound": "hbm", "kernel": "K3: field_sort + chunk_reduce + segment_finalize + sparse_update",
                                 "achieved": round(k3_bytes / k3_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(k3_bytes / k3_us / 1e3 / HBM_PEAK_GBS, 4),
-                                "algorithmic_bytes_per_step": k3_bytes, "distinct_rows": uniq, "us_per_step": round(k3_us, 1)}
+                                "algorithmic_bytes_per_step": k3_bytes, "distinct_rows": uniq, "us_per_step": round(k3_us, 1),
+                                "note": "K3 = index sort + replay of skipped Adam steps (exact mode) + chunk reduce + "
+                                        "segment finalize + touched-row update, each timed in a launch of its own"}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:

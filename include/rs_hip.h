@@ -225,10 +225,8 @@ int rs_ffm_rows_bwd(const float* G, const float* dout, int B, int F, int d, floa
  * segments (one per distinct non-padding row) and chunks (<= L entries, L = rs_sparse_window(d)). */
 size_t rs_sort_plan_ints(int F, int cap);
 int rs_sort_max_entries(void);
-/* Lists of more than 4096 entries given as one sub-list per field are sorted in two levels (tiles, then a merge)
- * unless switched off here; the plan written is the same.  Returns the previous setting.  (Tuning switch, no
- * counterpart in the reference.) */
-int rs_sort_two_level(int on);
+/* (Lists of more than 4096 entries given as one sub-list per field are sorted in two levels -- tiles, then a merge;
+ * several sub-lists per field always take the one-workgroup sort.  The plan written is the same either way.) */
 int rs_sparse_window(int d);
 int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_cnt, const int* pay_base, int pay_stride,
                        int nsrc, int F, int cap, int max_entries, int L, const int64_t* vocab,

@@ -125,7 +125,6 @@ _PLAIN = {
     "rs_colsum_noalloc_max_floats": (SZ, []),
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_sort_max_entries": (I, []),
-    "rs_sort_two_level": (I, [I]),
     "rs_merge_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),

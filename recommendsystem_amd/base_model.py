@@ -156,6 +156,19 @@ class BaseModel(nn.Module):
         self._engine = SparseTrainer(self, **kw)
         return self._engine
 
+    def _check_indices(self):
+        """The reference's nn.Embedding raises IndexError on an out-of-range index at once; the kernels here read the
+        padding row instead and set a device flag, which is read once per epoch (and every few hundred steps by the
+        trainers)."""
+        eng = self._engine
+        if eng is not None and hasattr(eng, "check"):
+            eng.check()
+        for mod in self.modules():
+            for name in ("_tab", "_tab1"):
+                holder = getattr(mod, name, None)
+                if holder is not None and getattr(holder, "layout", None) is not None:
+                    holder.layout.check_indices()
+
     def _flush_engine(self):
         """A touched-rows Adam trainer replays the skipped steps of a row only when the row is next read; before the
         tables are read or written as a whole every row is brought up to date."""
@@ -208,6 +221,7 @@ class BaseModel(nn.Module):
             train_loss += loss.item()
             if self.stop_training:
                 break
+        self._check_indices()
         self.last_train_loss = train_loss / max(len(loader), 1)
         self.logger.info(f"Train Loss: {self.last_train_loss:.6f}")
         self.eval_step()

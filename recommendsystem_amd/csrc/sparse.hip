@@ -378,13 +378,25 @@ __global__ __launch_bounds__(SORT_THREADS) void lists_rank_kernel(SortArgs a, in
 }
 
 template <int IT>
-__device__ __forceinline__ void tile_tail_body(const SortArgs& a, int f, int q, int tiles, const unsigned long long* merged64) {
+__device__ __forceinline__ void tile_tail_body(const SortArgs& a, int f, int q, int tiles, const unsigned long long* merged64,
+                                               int max_entries) {
     extern __shared__ __attribute__((aligned(16))) int tail_scratch[];           // [32] + [1024]
     constexpr int TS = SORT_THREADS * IT;
     const int t = threadIdx.x;
     int n = 0;
     for (int s = 0; s < a.nsrc; ++s) n += a.sub_cnt[s * a.F + f];
     const bool last = q == tiles - 1;
+    if (n > max_entries) {
+        // the lists hold more entries than the launch was sized for (lists_rank_kernel left the field alone): the field
+        // gets an empty plan, and counts[3] = -1 tells the host (SparsePlan.check)
+        if (last && t == 0) {
+            a.chunk_start[(long long)f * (a.cap + 1)] = 0;
+            a.seg_first_chunk[(long long)f * (a.cap + 1)] = 0;
+            int* c = a.counts + f * 4;
+            c[0] = 0; c[1] = 0; c[2] = 0; c[3] = -1;
+        }
+        return;
+    }
     if (q * TS >= n && !last) return;                                            // uniform over the workgroup
     const unsigned long long* src = merged64 + (long long)f * a.cap;
     const int lim = q * TS < n ? q * TS : n;
@@ -423,8 +435,9 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_rank_kernel(SortArgs a, int
 }
 
 template <int IT>
-__global__ __launch_bounds__(SORT_THREADS) void tile_tail_kernel(SortArgs a, int tiles, const unsigned long long* merged64) {
-    tile_tail_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles, merged64);
+__global__ __launch_bounds__(SORT_THREADS) void tile_tail_kernel(SortArgs a, int tiles, const unsigned long long* merged64,
+                                                                 int max_entries) {
+    tile_tail_body<IT>(a, blockIdx.x / tiles, blockIdx.x % tiles, tiles, merged64, max_entries);
 }
 
 // Level 1 of the two-level sort beside the gather (see sort_gather_kernel).
@@ -941,7 +954,6 @@ int window_for(int d) {
 
 }  // namespace
 
-static int g_two_level = 1;
 
 namespace {
 struct TwoLevelShape { int it, tiles; };
@@ -950,7 +962,7 @@ struct TwoLevelShape { int it, tiles; };
 constexpr int TWO_LEVEL_ABOVE = 4096;
 // tiles of 1024*it entries, at most SORT_MAX_TILES of them
 bool two_level_shape(int n, int nsrc, TwoLevelShape* s) {
-    if (!g_two_level || nsrc != 1 || n <= TWO_LEVEL_ABOVE) return false;
+    if (nsrc != 1 || n <= TWO_LEVEL_ABOVE) return false;
     s->it = n <= 4096 ? 1 : (n <= 8192 ? 2 : 4);
     s->tiles = rs_cdiv(n, SORT_THREADS * s->it);
     return s->tiles <= SORT_MAX_TILES;
@@ -978,7 +990,7 @@ int launch_rank_tail(const SortArgs& a, const TwoLevelShape& sh, unsigned long l
             attr = true;                                                                            \
         }                                                                                           \
         hipLaunchKernelGGL(tile_rank_kernel<IT>, grid, block, rsm, stream, a, sh.tiles, tiles64, merged64); \
-        hipLaunchKernelGGL(tile_tail_kernel<IT>, grid, block, tsm, stream, a, sh.tiles, merged64);  \
+        hipLaunchKernelGGL(tile_tail_kernel<IT>, grid, block, tsm, stream, a, sh.tiles, merged64, a.cap); \
     } while (0)
     if (sh.it == 1) RS_RANK_TAIL(1);
     else if (sh.it == 2) RS_RANK_TAIL(2);
@@ -997,9 +1009,8 @@ size_t rs_sort_plan_ints(int F, int cap) { return (size_t)F * (6 * (size_t)cap +
 
 int rs_sort_max_entries(void) { return SORT_THREADS * 16; }
 
-// Lists of more than 4096 entries given as one sub-list per field are sorted in two levels (tiles, then a merge)
-// unless this is switched off; the plan is the same either way.  Returns the previous setting.
-int rs_sort_two_level(int on) { const int was = g_two_level; g_two_level = on ? 1 : 0; return was; }
+// Lists of more than 4096 entries given as one sub-list per field (nsrc = 1) are sorted in two levels (tiles, then a
+// merge); several sub-lists per field always take the one-workgroup sort.  The plan is the same either way.
 
 
 // Per-field stable radix sort + segmentation (see file header).  `plan` is int32 scratch of
@@ -1095,9 +1106,9 @@ int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int
     const int tiles = rs_cdiv(max_entries, SORT_THREADS * it);
     const size_t tsm = (32 + SORT_THREADS) * sizeof(int);
     const dim3 grid(F * tiles), block(SORT_THREADS);
-    if (it == 1) hipLaunchKernelGGL(tile_tail_kernel<1>, grid, block, tsm, stream, a, tiles, merged64);
-    else if (it == 2) hipLaunchKernelGGL(tile_tail_kernel<2>, grid, block, tsm, stream, a, tiles, merged64);
-    else hipLaunchKernelGGL(tile_tail_kernel<4>, grid, block, tsm, stream, a, tiles, merged64);
+    if (it == 1) hipLaunchKernelGGL(tile_tail_kernel<1>, grid, block, tsm, stream, a, tiles, merged64, max_entries);
+    else if (it == 2) hipLaunchKernelGGL(tile_tail_kernel<2>, grid, block, tsm, stream, a, tiles, merged64, max_entries);
+    else hipLaunchKernelGGL(tile_tail_kernel<4>, grid, block, tsm, stream, a, tiles, merged64, max_entries);
     RS_CHECK_LAUNCH("rs_sparse_bwd_merge_lists");
     return RS_OK;
 }

@@ -372,6 +372,15 @@ class ShardedExchange:
                           "raise bucket_slack")
 
 
+def _reject_batchnorm(model, who: str):
+    """BatchNorm statistics would be those of one rank's slice of the global batch, and the running statistics of the
+    replicas would drift apart: not the single-device step on the union batch that these trainers promise."""
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            raise RSError(f"{who}: the model has BatchNorm layers, whose batch statistics are per rank here; build the "
+                          "model with normalization='ln' or None for multi-GPU training")
+
+
 # -------------------------------------------------------------------------------------------------
 # the distributed fused step
 # -------------------------------------------------------------------------------------------------
@@ -387,6 +396,7 @@ class DistributedTrainer(FusedTrainer):
                  bucket_slack: float = 1.5, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
+        _reject_batchnorm(model, "DistributedTrainer")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
@@ -545,6 +555,7 @@ class DistributedTrainer(FusedTrainer):
     # ---- utilities ---------------------------------------------------------------------------------
     def sync_to_model(self):
         """All-gather the shards into the model's (replicated) embedding parameters."""
+        self.check()
         self.flush()
         if self.has_emb:
             self.spec.unshard_into(self.tab.stacked, self._gather_shards(self.shard))
@@ -561,9 +572,14 @@ class DistributedTrainer(FusedTrainer):
         return [g[:k] for g, k in zip(self.comm.all_gather(pad), ns)]
 
     def check(self):
+        """Bucket overflow of the exchange (rows would be served as zeros and their gradients dropped) and index range:
+        raise.  Runs every check_every steps and before sync_to_model()."""
+        self._unchecked = 0
         for ex in self._ex.values():
             ex.check_overflow()
             ex.k.layout_own.check_indices()
+            ex.k.layout_req.check_indices()
+            ex.k.plan_own.check()
 
 
 # -------------------------------------------------------------------------------------------------
@@ -644,6 +660,7 @@ class ReplicatedTablesTrainer(FusedTrainer):
     gradients (and 1-dim gradients).  Limit: world * batch entries per field <= rs_merge_max_entries()."""
 
     def __init__(self, model, use_graph: bool = False, group=None, stage_cpu: bool = False, **kw):
+        _reject_batchnorm(model, "ReplicatedTablesTrainer")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         kw.pop("mode", None)
@@ -694,7 +711,10 @@ class ReplicatedTablesTrainer(FusedTrainer):
         self.flush()
 
     def check(self):
+        self._unchecked = 0
         self.layout.check_indices()
+        for rx in self._rp.values():
+            rx.k.gplan.check()
 
 
 # -------------------------------------------------------------------------------------------------
@@ -739,6 +759,7 @@ class DistributedSparseTrainer(SparseTrainer):
     def __init__(self, model, group=None, stage_cpu: bool = False, bucket_slack: float = 1.5, **kw):
         if kw.pop("use_graph", False):
             raise RSError("DistributedSparseTrainer: the step is issued eagerly (collectives between the launches)")
+        _reject_batchnorm(model, "DistributedSparseTrainer")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
@@ -823,6 +844,7 @@ class DistributedSparseTrainer(SparseTrainer):
 
     def sync_to_model(self):
         """All-gather the shards into the model's (replicated) table parameters."""
+        self.check()
         self.flush()
         for st in self._shards.values():
             shard = st["shard"].view(-1, 1) if st["kind"] == "lr" else st["shard"]
@@ -833,7 +855,10 @@ class DistributedSparseTrainer(SparseTrainer):
             st["spec"].unshard_into(st["holder"].stacked, [g[:k] for g, k in zip(self.comm.all_gather(pad), ns)])
 
     def check(self):
+        self._unchecked = 0
         for st in self._shards.values():
             for ex in st["ex"].values():
                 ex.check_overflow()
                 ex.k.layout_own.check_indices()
+                ex.k.layout_req.check_indices()
+                ex.k.plan_own.check()

@@ -145,6 +145,10 @@ class FusedTrainer:
         # the base hooks run the whole step on this GPU; subclasses that put collectives between the pieces turn it off
         self._fuse_small = type(self) is FusedTrainer
         self.last = {}
+        # device-side error flags (index out of range; on several GPUs also bucket overflow of the exchange) are read
+        # every check_every steps -- a host synchronisation -- and by check() before tables are read as a whole
+        self.check_every = 256
+        self._unchecked = 0
 
     # ------------------------------------------------------------------------------------------
     def _dense_params(self):
@@ -229,6 +233,12 @@ class FusedTrainer:
         for t in self.tables:
             if t.get("rs") is not None:
                 t["rs"].flush()
+
+    def check(self):
+        """Raise IndexError if a kernel saw an out-of-range index since the last check (the reference's nn.Embedding
+        raises at once; the kernels clamp such indices to the padding row and set a flag).  Device sync."""
+        self._unchecked = 0
+        self.layout.check_indices()
 
     def _check_tables(self):
         for tab, ver in self._versions:
@@ -602,6 +612,9 @@ class FusedTrainer:
         pre-staged batches): one graph is captured per distinct (idx, labels) buffer pair and
         replayed without any copy."""
         self._check_tables()
+        self._unchecked += 1
+        if self.check_every and self._unchecked >= self.check_every:
+            self.check()
         if not self.use_graph:
             with ops.use_workspace(self.ws):
                 return self._step_impl(idx, labels)

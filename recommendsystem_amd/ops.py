@@ -103,11 +103,15 @@ class Workspace:
     def __init__(self, device):
         self.device = torch.device(device)
         self._bufs = {}
+        self._retired = []
 
     def get(self, name: str, numel: int, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
-        """zero=True: the buffer starts zeroed and its users leave it zeroed (arrival counters)."""
+        """zero=True: the buffer starts zeroed and its users leave it zeroed (arrival counters).  A buffer that has
+        to grow is replaced, and the old one is kept alive: a captured HIP graph may still hold its address."""
         b = self._bufs.get(name)
         if b is None or b.numel() < numel or b.dtype != dtype:
+            if b is not None:
+                self._retired.append(b)
             mk = torch.zeros if zero else torch.empty
             b = mk(max(int(numel), 1), dtype=dtype, device=self.device)
             self._bufs[name] = b
@@ -547,6 +551,12 @@ class SparsePlan:
     def seg_rows(self):
         off = 3 * self.F * self.cap + self.F * (self.cap + 1)
         return self.plan[off:off + self.F * self.cap].view(self.F, self.cap)
+
+    def check(self):
+        """Raise if merge_lists was handed more entries for a field than it was sized for (device sync): such a field
+        gets an empty plan, i.e. its gradients are dropped."""
+        if bool((self.counts()[:, 3] < 0).any().item()):
+            raise RSError("sparse backward: a field's key lists held more entries than the merge was sized for")
 
     def columnar_lists(self, B: int):
         """Sub-list descriptors for a columnar [F, B] batch: one list per field."""

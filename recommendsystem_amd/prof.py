@@ -91,15 +91,18 @@ class KernelTimer:
         return False
 
     def summary(self):
-        """{(entry point, shape): dict(n, avg_us, total_us, work_per_launch, unit)} after a device sync."""
+        """{(entry point, shape): dict(n, avg_us, total_us, raw_avg_us, work_per_launch, unit)} after a device sync;
+        raw_* are the event durations as read, the others have the empty-pair overhead subtracted."""
         torch.cuda.synchronize()
-        agg = defaultdict(lambda: {"n": 0, "total_us": 0.0, "work": 0.0, "unit": ""})
+        agg = defaultdict(lambda: {"n": 0, "total_us": 0.0, "raw_total_us": 0.0, "work": 0.0, "unit": ""})
         for key, work, unit, s, e in self.records:
             a = agg[key]
             a["n"] += 1
             a["total_us"] += max(s.elapsed_time(e) * 1e3 - self.overhead_us, 0.0)
+            a["raw_total_us"] += s.elapsed_time(e) * 1e3
             a["work"] = work
             a["unit"] = unit
         for a in agg.values():
             a["avg_us"] = a["total_us"] / max(a["n"], 1)
+            a["raw_avg_us"] = a["raw_total_us"] / max(a["n"], 1)
         return dict(agg)

@@ -80,6 +80,11 @@ class SparseTrainer:
         self._plans: Dict[tuple, object] = {}
         self._partials = None
         self.last = {}
+        # scratch of this trainer's launches (split-K slabs, column-sum partials): private, so that a captured step
+        # never shares a buffer with another model or with module-path calls on the same device
+        self.ws = ops.Workspace(dev)
+        self.check_every = 256           # steps between reads of the device-side error flags (a host synchronisation)
+        self._unchecked = 0
 
     # ------------------------------------------------------------------------------------------
     def _flatten(self):
@@ -183,8 +188,10 @@ class SparseTrainer:
         backward, touched-rows reduction, optimizer -- is replayed from a HIP graph; resident=True promises that these
         exact tensors stay alive and are re-used (one graph per buffer pair, no copies), otherwise the batch is copied
         into the graph's static input buffers first."""
+        self._tick()
         if not self.use_graph:
-            return self._step_impl(self._columns(idx), labels)
+            with ops.use_workspace(self.ws):
+                return self._step_impl(self._columns(idx), labels)
         if resident:
             key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
             ent = self._graphs.get(key)
@@ -199,6 +206,20 @@ class SparseTrainer:
             ent["labels"].copy_(labels)
         ent["graph"].replay()
         return ent["loss"]
+
+    def _tick(self):
+        self._unchecked += 1
+        if self.check_every and self._unchecked >= self.check_every:
+            self.check()
+
+    def check(self):
+        """Raise IndexError if a lookup saw an out-of-range index since the last check (device sync)."""
+        self._unchecked = 0
+        for mod in self.model.modules():
+            for name in ("_tab", "_tab1"):
+                holder = getattr(mod, name, None)
+                if holder is not None and getattr(holder, "layout", None) is not None:
+                    holder.layout.check_indices()
 
     def _columns(self, idx):
         return {c: idx[i] for i, c in enumerate(self.model.embedding_layer.lookup_columns)}
@@ -225,7 +246,7 @@ class SparseTrainer:
             self._capture_stream = torch.cuda.Stream()
         side = self._capture_stream
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.use_workspace(self.ws):
             for _ in range(2):          # first launches set kernel attributes, size workspaces and plans
                 self._step_impl(x, labels)
         torch.cuda.current_stream().wait_stream(side)
@@ -243,7 +264,7 @@ class SparseTrainer:
                         st["rs"].last.zero_()
         restore()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool, stream=side):
+        with torch.cuda.graph(g, pool=self._graph_pool, stream=side), ops.use_workspace(self.ws):
             loss = self._step_impl(x, labels)
         if self._graph_pool is None:
             self._graph_pool = g.pool()
@@ -261,7 +282,9 @@ class SparseTrainer:
             if y.dtype not in (torch.int64, torch.float32):
                 y = y.float()
             return self.step_tensors(m.embedding_layer.index_matrix(x), y.contiguous())
-        return self._step_impl(inputs, self.model.labels_to_device(labels))
+        self._tick()
+        with ops.use_workspace(self.ws):
+            return self._step_impl(inputs, self.model.labels_to_device(labels))
 
     def _forward_backward(self, inputs, y, provider=None, grad_scale: float = 1.0):
         """The model's forward and autograd backward with captured table lookups; dense gradients land in flat_g."""

@@ -207,3 +207,38 @@ def test_fused_engine_sparse_adam_first_step_and_lazy_rows():
         for r in range(fm[c]["vocab_size"]):
             if r not in touched:
                 assert torch.equal(after[r], before[key][r])
+
+
+def test_tables_keep_their_storage_across_load_weights(tmp_path):
+    """fit() ends with load_weights(), which calls model.to(device) and load_state_dict(): the stacked tables must stay
+    the tensors the engine (and its captured graphs) hold, and training must go on moving the model's own tables."""
+    g = load_golden("train_deepfm_adam.npz")
+    m, feats = build_model(g)
+    eng = m.use_fused_step(mode="sparse", use_graph=True)
+    x = golden_batch(g, feats, "step0.x.")
+    y = {"label": torch.from_numpy(g["step0.label"])}
+    m.train_step(x, y)
+    ptr0 = m.embedding_layer._tab.stacked.data_ptr()
+    path = str(tmp_path / "w.model")
+    torch.save(m.state_dict(), path)
+    m.load_weights(path)
+    assert m.embedding_layer._tab.stacked.data_ptr() == ptr0
+    for c in m.embedding_layer.lookup_columns:            # per-column parameters are still views of the stacked table
+        w = m.embedding_layer.embedded_features[c].weight
+        assert ptr0 <= w.data_ptr() < ptr0 + m.embedding_layer._tab.stacked.numel() * 4
+    before = m.embedding_layer._tab.stacked.clone()
+    m.train_step(x, y)
+    assert (m.embedding_layer._tab.stacked != before).any()
+    assert eng.step_count.item() == 2
+
+
+def test_out_of_range_index_raises_like_nn_embedding():
+    g = load_golden("train_fm_sgd.npz")
+    m, feats = build_model(g)
+    eng = m.use_fused_step(mode="sparse")
+    x = golden_batch(g, feats, "step0.x.")
+    x = {c: v.clone() for c, v in x.items()}
+    x["C2"][3] = 10 ** 6
+    m.train_step(x, {"label": torch.from_numpy(g["step0.label"])})
+    with pytest.raises(IndexError):
+        eng.check()

@@ -93,27 +93,49 @@ def test_two_level_sort_writes_the_same_plan(B):
     layout = ops.FieldLayout(vocabs, dev)
     h = _lib.lib()
     cap = min(B + 5, h.rs_sort_max_entries())
-    plans = []
-    was = h.rs_sort_two_level(1)
-    try:
-        for on in (0, 1):
-            h.rs_sort_two_level(on)
-            p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
-            p.sort_columnar(idx.to(dev))
-            plans.append(p)
-        tiles_off = len(vocabs) * (6 * cap + 6)
-        assert torch.equal(plans[0].plan[:tiles_off], plans[1].plan[:tiles_off])
-        c = plans[1].counts().cpu()
-        assert (c[:, 0] == B).all() and int(c[2, 3]) == int((idx[2] == 0).sum())
-        # beside the gather
-        table = torch.randn(layout.total_rows, 16, device=dev)
-        p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
-        out = p.sort_and_gather(idx.to(dev), table, None, torch.zeros(1, device=dev))
-        assert torch.equal(p.plan[:tiles_off], plans[0].plan[:tiles_off])
-        rows = (idx + torch.tensor(layout.row_offsets)[:, None]).t().to(dev)
-        assert torch.equal(out["emb"], table[rows])
-    finally:
-        h.rs_sort_two_level(was)
+    F = len(vocabs)
+    # the one-workgroup sort of the same batch: two sub-lists per field, the second one empty (several sub-lists per
+    # field never take the two-level route)
+    one = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    f32 = torch.arange(F, dtype=torch.int32, device=dev)
+    z = torch.zeros(F, dtype=torch.int32, device=dev)
+    sub_off = torch.cat([f32 * B, z]); sub_cnt = torch.cat([torch.full_like(f32, B), z]); pay_base = torch.cat([f32, z])
+    _lib.call("rs_sparse_bwd_sort", _lib.ptr(idx.to(dev)), _lib.ptr(sub_off), _lib.ptr(sub_cnt), _lib.ptr(pay_base), F, 2, F,
+              cap, B, one.CHUNK, _lib.ptr(layout.vocab_t), _lib.ptr(layout.row_offset_t), _lib.ptr(one.plan), _lib.stream())
+    two = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    two.sort_columnar(idx.to(dev))
+    tiles_off = len(vocabs) * (6 * cap + 6)
+    assert torch.equal(one.plan[:tiles_off], two.plan[:tiles_off])
+    c = two.counts().cpu()
+    assert (c[:, 0] == B).all() and int(c[2, 3]) == int((idx[2] == 0).sum())
+    # beside the gather
+    table = torch.randn(layout.total_rows, 16, device=dev)
+    p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    out = p.sort_and_gather(idx.to(dev), table, None, torch.zeros(1, device=dev))
+    assert torch.equal(p.plan[:tiles_off], one.plan[:tiles_off])
+    rows = (idx + torch.tensor(layout.row_offsets)[:, None]).t().to(dev)
+    assert torch.equal(out["emb"], table[rows])
+
+
+def test_merge_reports_lists_longer_than_it_was_sized_for():
+    """merge_lists told max_entries = 40 while a field's lists hold 60 keys: the field gets an empty plan (no stale
+    segments) and SparsePlan.check() raises."""
+    from recommendsystem_amd import ops
+    from recommendsystem_amd._lib import RSError
+    dev = "cuda:0"
+    layout = ops.FieldLayout([1000, 1000], dev)
+    nsrc, per = 2, 30
+    keys = torch.zeros(nsrc * 2, per, dtype=torch.int64)
+    cnt = torch.tensor([30, 10, 30, 10], dtype=torch.int32)            # field 0: 60 keys, field 1: 20
+    for l in range(4):
+        keys[l, :int(cnt[l])] = torch.arange(1, int(cnt[l]) + 1) * (l + 1)
+    sf = torch.arange(nsrc * 2, dtype=torch.int32)
+    p = ops.SparsePlan(layout, cap=64, d=16, with_lr=False)
+    p.merge_lists(keys.to(dev).view(-1), (sf * per).to(dev), cnt.to(dev), (sf * per).to(dev), nsrc, 40)
+    c = p.counts().cpu()
+    assert c[0].tolist() == [0, 0, 0, -1] and int(c[1, 0]) == 20
+    with pytest.raises(RSError):
+        p.check()
 
 
 @pytest.mark.parametrize("nsrc,cap_b,vocabs", [

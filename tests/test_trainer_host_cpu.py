@@ -107,3 +107,17 @@ def test_bench_rank_failure_ends_the_launch():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode != 0 and "needs an MI355X" in r.stderr
+
+
+def test_distributed_trainers_reject_batchnorm_towers():
+    """Per-rank batch statistics are not the single-device step on the union batch: refused at construction, before
+    any process group is needed."""
+    import pytest
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd._lib import RSError
+    from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer, ReplicatedTablesTrainer
+    rec = data.criteo_x1_recorder(embedding_dim=4, batch_size=8, vocab_sizes=[5, 7])
+    m = models.DNN(rec, 1e-3, -1, hidden_dim_list=[8], normalization="bn")
+    for cls in (DistributedTrainer, ReplicatedTablesTrainer, DistributedSparseTrainer):
+        with pytest.raises(RSError, match="BatchNorm"):
+            cls(m)

@@ -1,0 +1,57 @@
+"""Copy the files tools/refresh_profiles.sh left under gpurun_out/profiles_rNN/ into profiles/rNN_* and check each one:
+a file that is empty, truncated or not what its name says stops the copy.
+
+    python tools/collect_profiles.py r02
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def jsonl(path, min_lines, need=()):
+    lines = [l for l in open(path).read().splitlines() if l.strip()]
+    assert len(lines) >= min_lines, f"{path}: {len(lines)} lines, expected at least {min_lines}"
+    rows = [json.loads(l) for l in lines]
+    for r in rows:
+        for k in need:
+            assert k in r, f"{path}: a line lacks {k!r}"
+    return rows
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src = os.path.join(ROOT, "gpurun_out", f"profiles_{rnd}")
+    dst = os.path.join(ROOT, "profiles")
+    assert os.path.isdir(src), f"{src} not found: run tools/refresh_profiles.sh {rnd} on the GPU box first"
+    b = jsonl(os.path.join(src, "bench_n1.json"), 1, ("metric", "value", "roofline", "cpu_baseline"))[0]
+    assert b["roofline"] and b["cpu_baseline"], "bench line without roofline / cpu_baseline"
+    v = jsonl(os.path.join(src, "bench_variants.jsonl"), 17, ("metric", "value", "config"))
+    kinds = [r["config"]["embedding_update"].split(",")[0] for r in v]
+    assert "dense" in kinds and any("lazy" in r["config"]["embedding_update"] for r in v), "variants lack the dense / lazy lines"
+    it = jsonl(os.path.join(src, "interact_roofline.jsonl"), 30, ("kernel", "avg_us"))
+    names = {r["kernel"] for r in it}
+    for k in ("pnn_inner_fwd", "pnn_outer_bwd", "dcn_cross_bwd", "afm_bwd"):
+        assert any(n.startswith(k) for n in names), f"interact_roofline.jsonl lacks {k}"
+    for name in ("bench_kernel_stats.csv", "interact_kernel_stats.csv"):
+        rows = list(csv.DictReader(open(os.path.join(src, name))))
+        assert len(rows) >= 10 and "AverageNs" in rows[0], f"{name}: not a rocprofv3 kernel_stats file"
+    assert any("gemm_f32_dma_kernel" in r["Name"] for r in csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))))
+    assert any("pnn_inner" in r["Name"] for r in csv.DictReader(open(os.path.join(src, "interact_kernel_stats.csv"))))
+    sb = open(os.path.join(src, "step_breakdown.txt")).read()
+    assert "us/step" in sb and "gemm_f32_dma_kernel" in sb, "step_breakdown.txt is not a step breakdown"
+    t = json.load(open(os.path.join(src, "pmc_traffic.json")))
+    assert any(k.startswith("gemm_f32_dma_kernel") for k in t["kernels"]) and any("gather" in k for k in t["kernels"])
+    for name in ("bench_n1.json", "bench_variants.jsonl", "interact_roofline.jsonl", "bench_kernel_stats.csv",
+                 "interact_kernel_stats.csv", "step_breakdown.txt", "pmc_traffic.json"):
+        shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
+        print("profiles/" + f"{rnd}_{name}")
+    # bench.py reads the traffic counters from the newest round's file
+    shutil.copyfile(os.path.join(src, "pmc_traffic.json"), os.path.join(dst, "pmc_traffic.json"))
+
+
+if __name__ == "__main__":
+    main()

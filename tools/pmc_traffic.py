@@ -1,4 +1,5 @@
-"""profiles/pmc_traffic.json from the two counter passes of tools/pmc_bench.sh.
+"""pmc_traffic.json (written beside the passes; tools/collect_profiles.py copies it into profiles/) from the two counter
+passes of tools/refresh_profiles.sh / tools/pmc_bench.sh.
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE counts 128-byte read requests as
 64 bytes, so it is doubled.  Per kernel name: launches, mean read / written bytes per launch."""
@@ -12,10 +13,13 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+BASE = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
+
+
 def load(d, counter):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True)
+    files = glob.glob(os.path.join(BASE, d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
-        raise SystemExit(f"no counter csv under gpurun_out/{d}")
+        raise SystemExit(f"no counter csv under {BASE}/{d}")
     agg = defaultdict(lambda: [0, 0.0])
     with open(files[0]) as f:
         for r in csv.DictReader(f):
@@ -42,7 +46,7 @@ def main():
            "corrections": "values are KiB per dispatch; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B)",
            "dominant_kernel": "gemm_f32_dma_kernel (all MLP GEMM launches of a step)",
            "dominant_kernel_hbm_bytes_per_launch": dom, "kernels": kernels}
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(BASE, "pmc_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, "dominant bytes/launch:", dom)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["read_bytes_per_launch"])[:14]:

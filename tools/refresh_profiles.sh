@@ -1,11 +1,64 @@
 #!/bin/bash
-# Everything under profiles/ in one GPU-box call: default bench line, its rocprofv3 kernel trace and step breakdown,
-# the bench variants and the interaction-kernel rooflines.  Results land in gpurun_out/; copy what is to be kept.
+# Everything that ends up under profiles/ for one round, in one GPU-box call.  Results land in gpurun_out/profiles_rNN/
+# (the only directory a GPU call brings back); tools/collect_profiles.py then copies them into profiles/rNN_* in the
+# repository and checks that every file is what it claims to be.
+# usage: tools/refresh_profiles.sh r02
 set -u
+R=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/profiles_$R
 cd "$ROOT"
-timeout -k 10 400 python bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err || exit 1
-tools/profile_bench.sh > gpurun_out/profile_bench.log 2>&1 || exit 1
-tools/bench_variants.sh 2> gpurun_out/bench_variants.err || exit 1
-tools/profile_interact.sh > gpurun_out/profile_interact.log 2>&1 || exit 1
+rm -rf "$OUT" && mkdir -p "$OUT"
+step() { echo "== $*" >&2; }
+
+step "default bench line"
+timeout -k 10 400 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || exit 1
+
+step "kernel trace of the same command"
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- \
+    python3 "$ROOT/bench.py" --cpu-baseline 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err" ) || exit 1
+find "$OUT/prof" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
+trace=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
+python tools/trace_steps.py "$trace" 50 > "$OUT/step_breakdown.txt" || exit 1
+rm -rf "$OUT/prof"
+
+step "bench variants"
+V=$OUT/bench_variants.jsonl
+: > "$V"
+run() { echo "== bench.py $*" >&2; timeout -k 10 400 python bench.py "$@" >> "$V" 2>> "$OUT/bench_variants.err" || exit 1; }
+run --exact-adam 0 --cpu-baseline 0                      # lazy Adam: what the exact replay costs
+run --mode dense --cpu-baseline 0 --steps 20             # the reference's dense optimizer sweep
+run --distinct-batches 64 --steps 128 --warmup 64 --cpu-baseline 0 --event-pass 0    # rows come back after 64 steps
+run --uniform 1 --cpu-baseline 0
+run --fields 26 --cpu-baseline 0
+run --cpu-threads 1 --cpu-seconds 15 --event-pass 0
+run --model fm --cpu-baseline 0
+for m in ffm pnn_inner dcn nfm afm; do
+  run --model $m --steps 20 --warmup 5 --cpu-baseline 0
+done
+run --model pnn_inner --activation tanh --steps 20 --warmup 5 --cpu-baseline 0       # a 1-wide head that is not a dead ReLU
+for m in dcn pnn_inner; do
+  run --model $m --batch 16384 --steps 10 --warmup 3 --cpu-baseline 0
+done
+run --batch 16384 --steps 20 --warmup 5 --cpu-baseline 0
+run --model pnn --activation tanh --steps 5 --warmup 2 --cpu-baseline 0 --distinct-batches 2
+
+step "interaction kernels"
+timeout -k 10 400 python tools/bench_interact.py 4096 16384 > "$OUT/interact_roofline.jsonl" 2> "$OUT/interact.err" || exit 1
+( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/iprof" -o interact -- \
+    python3 "$ROOT/tools/bench_interact.py" 4096 > /dev/null 2> "$OUT/interact_prof.err" ) || exit 1
+find "$OUT/iprof" -name "*kernel_stats.csv" -exec cp {} "$OUT/interact_kernel_stats.csv" \;
+rm -rf "$OUT/iprof"
+
+step "HBM traffic counters (one counter per pass, no tracing)"
+ARGS="--steps 4 --warmup 2 --graph 0 --cpu-baseline 0 --distinct-batches 2 --event-pass 0"
+for c in FETCH_SIZE WRITE_SIZE; do
+    D=$OUT/pmc_$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+    mkdir -p "$D"
+    ( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$D" -o pmc -- \
+        python3 "$ROOT/bench.py" $ARGS > "$D/bench.json" 2> "$D/bench.err" ) || exit 1
+done
+python tools/pmc_traffic.py "$OUT" || exit 1
+rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
+ls -la "$OUT"
 echo refreshed
