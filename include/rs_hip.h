@@ -122,6 +122,13 @@ int rs_ln_fwd(const float* z, int M, int N, const float* gamma, const float* bet
 int rs_ln_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gamma, int M, int N,
               int act, float* dz, float* dy, float* dyxhat, rs_stream_t stream);
 int rs_add_f32(const float* a, const float* b, float* y, long long n, rs_stream_t stream);   /* residual add, Layers.py:94 */
+/* nn.Dropout in training mode (Layers.py:33-37,46): y[i] = keep(i) ? x[i]/(1-p) : 0.  keep(i) comes from Philox4x32-10
+ * keyed by `seed` with counter (i/4, call, salt): element i's bit depends only on (seed, salt, call, i), so calling it
+ * again on the gradient with the same four numbers is the backward pass and no mask is stored.  call = call_host +
+ * *call_dev (call_dev, a device counter such as the optimizer's step count, may be null): a replayed HIP graph then
+ * draws a fresh mask per replay.  The reference's masks come from torch's generator; only the distribution matches. */
+int rs_dropout_apply(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned salt,
+                     unsigned long long call_host, const long long* call_dev, rs_stream_t stream);
 int rs_axpy_f32(float a, const float* x, float* y, long long n, rs_stream_t stream);         /* L2 term, BaseModel.py:214-231 */
 int rs_loss_add_reg(float* loss, const float* partials, const int* seg_end, const float* coef, int nseg,
                     rs_stream_t stream);

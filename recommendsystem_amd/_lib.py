@@ -83,6 +83,7 @@ _SIGS = {
     "rs_ln_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_ln_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_add_f32": [c_f32p, c_f32p, c_f32p, L, c_stream],
+    "rs_dropout_apply": [c_f32p, c_f32p, L, F, C.c_ulonglong, C.c_uint, C.c_ulonglong, c_i64p, c_stream],
     "rs_axpy_f32": [F, c_f32p, c_f32p, L, c_stream],
     "rs_loss_add_reg": [c_f32p, c_f32p, c_i32p, c_f32p, I, c_stream],
     # shard.hip

@@ -507,6 +507,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- dropout (nn.Dropout in training mode, model/utils/Layers.py:33-37,46) -------------------------------------
+// y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) drawn from a counter-based generator (Philox4x32-10): the bits of
+// element i depend only on (seed, salt, call, i), so the backward pass regenerates the forward's mask from the same
+// four numbers instead of storing it.  One Philox block serves four consecutive elements.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                            float p, unsigned long long seed, unsigned salt,
+                                                            unsigned long long call_host,
+                                                            const long long* __restrict__ call_dev) {
+    const unsigned long long call = call_host + (call_dev ? (unsigned long long)*call_dev : 0ull);
+    // keep iff u >= p * 2^32 (u uniform on 32 bits): P(keep) = 1 - p
+    const double thr_d = (double)p * 4294967296.0;
+    const unsigned thr = thr_d >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)thr_d;
+    const bool drop_all = p >= 1.f;
+    const float scale = drop_all ? 0.f : 1.f / (1.f - p);
+    const long long nblk = (n + 3) / 4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        unsigned c[4] = {(unsigned)b, (unsigned)((unsigned long long)b >> 32), (unsigned)call, salt ^ (unsigned)(call >> 32)};
+        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        const long long i0 = b * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long long i = i0 + e;
+            if (i < n) y[i] = (!drop_all && c[e] >= thr) ? x[i] * scale : 0.f;
+        }
+    }
+}
+
 // y = a + b (residual add), flat
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ y, long long n) {
@@ -741,6 +781,20 @@ int rs_loss_add_reg(float* loss, const float* partials, const int* seg_end, cons
     RS_CHECK_ARG(loss && partials && seg_end && coef && nseg >= 0, "rs_loss_add_reg: bad arguments");
     hipLaunchKernelGGL(loss_add_reg_kernel, dim3(1), dim3(64), 0, stream, loss, partials, seg_end, coef, nseg);
     RS_CHECK_LAUNCH("rs_loss_add_reg");
+    return RS_OK;
+}
+
+// y = dropout_mask(seed, salt, call) * x / (1 - p); the same call on a gradient is the backward pass.
+// call = call_host + *call_dev (call_dev may be null): a device-side step counter keeps a replayed HIP graph drawing
+// fresh masks.  x == y (in place) is allowed.
+int rs_dropout_apply(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned salt,
+                     unsigned long long call_host, const long long* call_dev, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "rs_dropout_apply: bad arguments");
+    RS_CHECK_ARG(p >= 0.f && p <= 1.f, "rs_dropout_apply: dropout probability has to be between 0 and 1, but got %f", (double)p);
+    if (n == 0) return RS_OK;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, stream, x, y, n, p, seed, salt,
+                       call_host, call_dev);
+    RS_CHECK_LAUNCH("rs_dropout_apply");
     return RS_OK;
 }
 

@@ -100,8 +100,6 @@ class FusedTrainer:
         for b in self.blocks:
             if not isinstance(b, MLPBlock):
                 raise RSError("FusedTrainer: the deep tower must be a stack of MLPBlock")
-            if b.dropout.p:
-                raise RSError("FusedTrainer: dropout > 0 is not part of the fused step")
 
         emb = model.embedding_layer
         self.cols = emb.lookup_columns
@@ -125,7 +123,7 @@ class FusedTrainer:
         last = self.blocks[-1] if self.blocks else None
         self._head_fast = bool(last is not None and last.fc.out_features == 1 and not last.normalization
                                and last._act in _FUSABLE and last.fc.in_features % 4 == 0
-                               and last.fc.in_features <= 1024)
+                               and last.fc.in_features <= 1024 and not last.dropout.p)
         self._flatten_dense()
         self._alloc_state()
         self._plans: Dict[int, ops.SparsePlan] = {}
@@ -314,6 +312,8 @@ class FusedTrainer:
                 h, c = Fn.mlp_block_fwd(h, b.fc.weight.data, b.fc.bias.data, b._act, b.normalization or None, gamma,
                                         beta, slope, self.model.training, rm, rv, eps)
                 cs.append(c)
+                if self._drops(b):
+                    h = self._dropout(h, b)              # c.h stays the activation before the mask (act' needs it)
             ctx["mlp"] = cs
             if h is not None:
                 parts.append(h.view(B))
@@ -371,6 +371,15 @@ class FusedTrainer:
         else:
             plan.update(self.opt, self.hyper, self.scal, **kw)
 
+    def _drops(self, b) -> bool:
+        """Block b's output goes through dropout in this pass (Layers.py:33-37,46)."""
+        return b is not None and bool(b.dropout.p) and self.model.training
+
+    def _dropout(self, x, b):
+        """The mask of block b at the current step, applied to an activation (forward) or to a gradient (backward):
+        the device step counter numbers it, so both passes of a step -- and every replay of a captured step -- agree."""
+        return ops.dropout_apply(x, b.dropout.p, torch.initial_seed(), b.dropout.salt, 0, self.step_count)
+
     def _bump_bn_counters(self):
         for b in self.blocks:
             if b.normalization == "bn" and self.model.training:
@@ -411,7 +420,8 @@ class FusedTrainer:
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
         csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None
         head_prev = self.blocks[-2] if head_fast and len(self.blocks) > 1 else None
-        head_fuse_prev = head_prev is not None and not head_prev.normalization and head_prev._act in (1, 2, 3)
+        head_fuse_prev = (head_prev is not None and not head_prev.normalization and head_prev._act in (1, 2, 3)
+                          and not self._drops(head_prev))
         head_both = head_fast and ctx["head_in"].shape[1] <= 1024
         if head_both:
             # the 1-wide last block, the loss, dL/dlogit and the block's backward in one launch
@@ -460,7 +470,8 @@ class FusedTrainer:
             if head_fast:
                 _, xin, _ = cs[top]
                 prev = self.blocks[top - 1] if top > 0 else None
-                fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
+                fuse_prev = (prev is not None and not prev.normalization and prev._act in (1, 2, 3)
+                             and not self._drops(prev))
                 # dX, dW of the head and (when the previous act' is fused) the previous block's bias gradient
                 if head_both:
                     dh = head["dx"]
@@ -468,12 +479,19 @@ class FusedTrainer:
                     dh = ops.head_bwd(head["dzh"], lastb.fc.weight.data.view(-1), xin, prev._act if fuse_prev else 0, csp,
                                       dW_out=self.gviews[id(lastb.fc.weight)].view(-1),
                                       dbp_out=self.gviews[id(prev.fc.bias)] if fuse_prev else None)
+                if self._drops(prev):
+                    dh = self._dropout(dh, prev)         # the head read the masked activation
+                    keep.append(dh)
                 dz_ready = db_done = fuse_prev
                 top -= 1
+            if not head_fast and self._drops(self.blocks[top]):
+                dh = self._dropout(dh, self.blocks[top])     # the loss read the masked output of the last block
+                keep.append(dh)
             for i in range(top, -1, -1):
                 b, c = self.blocks[i], cs[i]
                 prev = self.blocks[i - 1] if i > 0 else None
-                fuse_prev = prev is not None and not prev.normalization and prev._act in (1, 2, 3)
+                fuse_prev = (prev is not None and not prev.normalization and prev._act in (1, 2, 3)
+                             and not self._drops(prev))
                 if not b.normalization and b._act in _FUSABLE:
                     dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
                     keep.append(dzl)
@@ -503,6 +521,8 @@ class FusedTrainer:
                     dh = r["dx"]
                     keep.append(r)
                     db_done = False
+                if self._drops(prev):
+                    dh = self._dropout(dh, prev)         # this block read the masked activation of the previous one
                 dz_ready = fuse_prev
                 keep.append(dh)
             # the bias-gradient finishes and the weight-gradient split-K reduces: beside the first launch of the

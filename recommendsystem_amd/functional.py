@@ -81,6 +81,7 @@ class TableCapture:
         self.splitk = splitk
         # on_lookup(holder, idx): called before a local table is read (the trainer brings the rows up to date)
         self.on_lookup = on_lookup
+        self.rng_step = None     # device int64 counter that numbers the dropout masks of this pass (the trainer's step count)
         self._sunk = set()
         self._idx = {}           # (id of the batch dict, columns) -> (batch dict, index matrix): one stack per forward
 
@@ -288,6 +289,51 @@ class _MLPBlockFn(torch.autograd.Function):
 
 def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):
     return _MLPBlockFn.apply(x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps)
+
+
+class _DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode (Layers.py:33-37,46) on the HIP kernel: the mask is a function of
+    (seed, salt, call), so the backward pass regenerates it instead of keeping it."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, salt, call_no, call_dev):
+        ctx.args = (p, seed, salt, call_no, call_dev)
+        return ops.dropout_apply(x.contiguous(), p, seed, salt, call_no, call_dev)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, salt, call_no, call_dev = ctx.args
+        return ops.dropout_apply(g.contiguous(), p, seed, salt, call_no, call_dev), None, None, None, None, None
+
+
+_dropout_calls = 0
+
+
+def dropout(x, p: float, salt: int):
+    """Training-mode dropout of x.  Inside a trainer's captured step the trainer's device step counter numbers the
+    call (a replayed HIP graph draws a fresh mask every step); elsewhere a host-side call counter does."""
+    global _dropout_calls
+    cap = TableCapture.active
+    call_dev = getattr(cap, "rng_step", None) if cap is not None else None
+    call_no = 0
+    if call_dev is None:
+        _dropout_calls += 1
+        call_no = _dropout_calls
+    return _DropoutFn.apply(x, float(p), torch.initial_seed(), int(salt), call_no, call_dev)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)
 
 
 class _ResidualFn(torch.autograd.Function):

@@ -209,6 +209,24 @@ class Linear(nn.Linear):
         return Fn.mlp_block(x2d, self.weight, self.bias, 0, None, None, None, None, self.training, None, None)
 
 
+class Dropout(nn.Dropout):
+    """nn.Dropout (same constructor, no parameters) whose training-mode forward and backward run on the HIP kernel
+    (Layers.py:33-37,46).  The masks come from a counter-based generator keyed by torch's seed, not from torch's
+    generator: same distribution, different bits."""
+
+    _salts = 0
+
+    def __init__(self, p=0.5):
+        super().__init__(p)
+        Dropout._salts += 1
+        self.salt = Dropout._salts          # tells the masks of different layers apart
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        return Fn.dropout(x, self.p, self.salt)
+
+
 def _activation_module(name: str):
     name = name.lower()
     if name == "relu":
@@ -238,7 +256,7 @@ class MLPBlock(nn.Module):
             self.norm_layer = nn.LayerNorm(output_dim)
         else:
             raise ValueError("normalization must be either 'bn' or 'ln' or None")
-        self.dropout = nn.Dropout(dropout_rate) if dropout_rate else nn.Dropout(0)
+        self.dropout = Dropout(dropout_rate) if dropout_rate else Dropout(0)
 
     def _norm_args(self):
         if not self.normalization:
@@ -278,7 +296,7 @@ class ResidualMLPBlock(nn.Module):
             self.norm_layer = nn.LayerNorm(output_dim)
         else:
             raise ValueError("normalization must be either 'bn' or 'ln'")
-        self.dropout = nn.Dropout(dropout_rate) if dropout_rate else nn.Dropout(0)
+        self.dropout = Dropout(dropout_rate) if dropout_rate else Dropout(0)
         self.downsample = nn.Linear(input_dim, output_dim) if input_dim != output_dim else None
 
     _norm_args = MLPBlock._norm_args
@@ -286,10 +304,15 @@ class ResidualMLPBlock(nn.Module):
     def forward(self, x):
         bs = x.size()[0]
         x = x.reshape(bs, -1)
-        if self.dropout.p and self.training:
-            raise RSError("ResidualMLPBlock: dropout between the block and the residual add is not provided")
         gamma, beta, rm, rv, eps = self._norm_args()
         Wd = self.downsample.weight if self.downsample is not None else None
         bd = self.downsample.bias if self.downsample is not None else None
+        if self.dropout.p and self.training:
+            # dropout sits between the block and the residual add (Layers.py:88-94): the three pieces one by one
+            out = Fn.mlp_block(x, self.fc.weight, self.fc.bias, self._act, self.normalization, gamma, beta, None,
+                               self.training, rm, rv, eps)
+            out = self.dropout(out)
+            identity = x if Wd is None else Fn.mlp_block(x, Wd, bd, 0, None, None, None, None, self.training, None, None)
+            return Fn.add(identity, out)
         return Fn.residual_block(x, self.fc.weight, self.fc.bias, gamma, beta, Wd, bd, self._act, self.normalization,
                                  self.training, rm, rv, eps)

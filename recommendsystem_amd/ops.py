@@ -883,6 +883,19 @@ def ln_bwd(dh, h, xhat, rstd, gamma, act: int):
     return dz, colsum(dyx), colsum(dy)
 
 
+def dropout_apply(x: torch.Tensor, p: float, seed: int, salt: int, call_no: int = 0,
+                  call_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x * mask / (1 - p) with the mask of (seed, salt, call_no + *call_dev); applied to a gradient with the same numbers
+    it is the backward pass of the dropout that produced the activation."""
+    _chk(x, torch.float32, "x")
+    if call_dev is not None:
+        _chk(call_dev, torch.int64, "call_dev", (1,))
+    y = out if out is not None else torch.empty_like(x)
+    call("rs_dropout_apply", ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(salt) & 0xFFFFFFFF,
+         int(call_no) & 0xFFFFFFFFFFFFFFFF, ptr(call_dev), stream())
+    return y
+
+
 def add(a, b):
     y = torch.empty_like(a)
     call("rs_add_f32", ptr(a), ptr(b), ptr(y), a.numel(), stream())

@@ -300,6 +300,7 @@ class SparseTrainer:
         splitk = ops.SplitKParts(ops.default_workspace(self.device)) if direct else None
         with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk,
                              on_lookup=self._on_lookup if self.exact else None) as cap:
+            cap.rng_step = self.step_count          # numbers the dropout masks: fresh ones at every (replayed) step
             out = m.forward(inputs)
             loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
