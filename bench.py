@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--optimizer", type=str, default="Adam")
     p.add_argument("--activation", type=str, default="ReLU",
                    help="activation of the MLP blocks (the reference's default ReLU also sits on the 1-wide last block)")
+    p.add_argument("--dropout", type=float, default=0.0,
+                   help="dropout_rate of the first MLP block (the reference's scripts pass one; 0 = none)")
     p.add_argument("--mode", type=str, default="sparse", choices=["sparse", "dense"])
     p.add_argument("--exact-adam", type=int, default=1,
                    help="touched-rows Adam/AdamW with the reference's dense semantics (a row's skipped zero-gradient steps "
@@ -91,6 +93,8 @@ def build(args, device):
     kw = dict(optimizer_type=args.optimizer)
     if args.model in ("deepfm", "dnn", "widedeep", "pnn", "pnn_inner", "dcn", "nfm"):
         kw["activation_func"] = args.activation
+        if args.dropout > 0:
+            kw["dropout_rate"] = args.dropout
     if args.model == "deepfm":
         m = models.DeepFM(rec, 1e-3, gpu, hidden_dim_list=hidden, normalization=None, **kw)
     elif args.model == "fm":
@@ -424,7 +428,7 @@ def main():
                                       else "26 categorical fields (log-spaced 10..1e6)")
                                    + f", embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
-                       "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer,
+                       "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer, "dropout": args.dropout,
                        "embedding_update": args.mode if args.mode == "dense" or args.optimizer not in ("Adam", "AdamW")
                        else ("sparse, exact: touched rows only, a row's skipped zero-gradient steps replayed before it is read "
                              "(the reference's dense optimizer)" if getattr(eng, "exact", False)

@@ -29,7 +29,7 @@ def main():
     assert os.path.isdir(src), f"{src} not found: run tools/refresh_profiles.sh {rnd} on the GPU box first"
     b = jsonl(os.path.join(src, "bench_n1.json"), 1, ("metric", "value", "roofline", "cpu_baseline"))[0]
     assert b["roofline"] and b["cpu_baseline"], "bench line without roofline / cpu_baseline"
-    v = jsonl(os.path.join(src, "bench_variants.jsonl"), 17, ("metric", "value", "config"))
+    v = jsonl(os.path.join(src, "bench_variants.jsonl"), 19, ("metric", "value", "config"))
     kinds = [r["config"]["embedding_update"].split(",")[0] for r in v]
     assert "dense" in kinds and any("lazy" in r["config"]["embedding_update"] for r in v), "variants lack the dense / lazy lines"
     it = jsonl(os.path.join(src, "interact_roofline.jsonl"), 30, ("kernel", "avg_us"))
