@@ -13,6 +13,8 @@ from . import ops
 from .ops import ACT_CODES, FieldLayout, SparsePlan
 
 _FUSABLE = (0, 1, 2, 3)      # none / relu / tanh / leakyrelu can ride in the GEMM epilogue
+_ONE_WIDE_MAX_K = 1024       # widest input rs_head_bwd takes
+_PAD_MIN_K = 64              # narrower odd inputs are not worth the two padding copies
 
 
 def stack_columns(x, cols) -> torch.Tensor:
@@ -199,15 +201,37 @@ def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
 # MLP blocks
 # -------------------------------------------------------------------------------------------------
 class MLPCtx:
-    __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps")
+    __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps", "k", "one")
+
+
+def _pad_columns(t, pad: int):
+    """[M, K] -> [M, K + pad] with zero columns behind (one copy and a fill of the pad columns only)."""
+    out = t.new_empty((t.shape[0], t.shape[1] + pad))
+    out[:, :t.shape[1]].copy_(t)
+    out[:, t.shape[1]:].zero_()
+    return out
 
 
 def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=None, slope=None, training=True,
-                  running_mean=None, running_var=None, eps=1e-5):
-    """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx)."""
+                  running_mean=None, running_var=None, eps=1e-5, allow_pad=False):
+    """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx).
+
+    allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width)."""
     c = MLPCtx()
     c.x, c.W, c.act, c.norm, c.gamma, c.slope, c.eps = x2d, W, act, norm, gamma, slope, eps
     c.z = c.y = c.xhat = c.var = c.rstd = None
+    c.k = W.shape[1]
+    # a 1-wide plain layer is a dot product per row, not a GEMM
+    c.one = (W.shape[0] == 1 and not norm and act in _FUSABLE and b is not None and W.shape[1] <= _ONE_WIDE_MAX_K
+             and (W.shape[1] % 4 != 0 or (x2d.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)))
+    if c.one:
+        c.h = ops.rowdot_fwd(x2d, W.reshape(-1), b, act).view(-1, 1)
+        return c.h, c
+    if allow_pad and c.k % 4 != 0 and c.k >= _PAD_MIN_K and x2d.shape[0] >= 256:
+        # rows of an odd width are not 16-byte aligned and would take the register-staged GEMM; zero columns up to
+        # the next multiple of four change no sum and let all three products of the block run on the DMA kernel
+        c.x = x2d = _pad_columns(x2d, 4 - c.k % 4)
+        c.W = W = _pad_columns(W.detach(), 4 - c.k % 4)
     fus = act if act in _FUSABLE else 0
     if not norm:
         if act in _FUSABLE:
@@ -232,13 +256,16 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
 
 
 def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0,
-                  defer_reduce=None):
+                  defer_reduce=None, colsum_parts=None, dbp_out=None, db_done=False):
     """Backward of one block.  Returns dict(dx, dW, db, dgamma, dbeta, dslope).
 
     dz_ready: `dh` already is dL/dz (the caller fused act' into the GEMM that produced it).
     mulsrc/mul_act: fuse the PREVIOUS block's act' into this block's dx GEMM, so that the returned
-    dx is the previous block's dL/dz."""
-    out = {"dgamma": None, "dbeta": None, "dslope": None}
+    dx is the previous block's dL/dz.
+    colsum_parts/dbp_out: with a fused act', the launch that produces dx also leaves the partial column sums of dx --
+    the previous block's bias gradient -- with the collector (valid in dbp_out after its finish()).
+    db_done: this block's bias gradient is already on its way (the block above left it with the collector)."""
+    out = {"dgamma": None, "dbeta": None, "dslope": None, "db": None}
     fus = c.act if c.act in _FUSABLE else 0
     if not c.norm:
         if dz_ready:
@@ -257,9 +284,49 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             dz, out["dgamma"], out["dbeta"] = ops.bn_bwd(dh, hh, c.xhat, fus, c.gamma, c.var, c.eps)
         else:
             dz, out["dgamma"], out["dbeta"] = ops.ln_bwd(dh, hh, c.xhat, c.rstd, c.gamma, fus)
+    if getattr(c, "one", False):
+        # 1-wide layer: dx, the partial sums of dW and (with a fused act') of the previous block's bias gradient
+        # come out of one launch
+        own = colsum_parts is None
+        parts = colsum_parts if colsum_parts is not None else ops.ColsumParts(ops.default_workspace(dz.device))
+        dW = dW_out if dW_out is not None else torch.empty_like(c.W)
+        if not db_done:
+            out["db"] = ops.colsum(dz.view(-1, 1), out=db_out)
+        out["dx"] = ops.head_bwd(dz.reshape(-1), c.W.reshape(-1), c.x, mul_act if mulsrc is not None else 0, parts,
+                                 dW_out=dW.view(-1), dbp_out=dbp_out if mulsrc is not None else None)
+        if own:
+            parts.finish()
+        out["dbp_left"] = mulsrc is not None and dbp_out is not None
+        out["dW"] = dW
+        out["dz"] = dz
+        return out
+    if c.x.shape[1] != c.k:
+        # padded input width (mlp_block_fwd): the pad columns of dW and dx are zero and are cut off again
+        dWp = ops.gemm(dz, c.x, a_mc=True, b_nc=True)
+        if dW_out is not None:
+            dW_out.copy_(dWp[:, :c.k])
+            out["dW"] = dW_out
+        else:
+            out["dW"] = dWp[:, :c.k]
+        if not db_done:
+            out["db"] = ops.colsum(dz, out=db_out)
+        out["dx"] = ops.gemm(dz, c.W, b_nc=True)[:, :c.k] if need_dx else None
+        if need_dx and mulsrc is not None:
+            out["dx"] = ops.act_bwd(out["dx"].contiguous(), mul_act, h=mulsrc)[0]
+        out["dz"] = dz
+        return out
     out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
-    out["db"] = ops.colsum(dz, out=db_out)
-    out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act) if need_dx else None
+    if not db_done:
+        out["db"] = ops.colsum(dz, out=db_out)
+    if need_dx:
+        if mulsrc is not None and colsum_parts is not None and dbp_out is not None:
+            colsum_parts.expect(dbp_out)
+            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts)
+            out["dbp_left"] = True
+        else:
+            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act)
+    else:
+        out["dx"] = None
     out["dz"] = dz
     return out
 
@@ -267,10 +334,15 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
 class _MLPBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps):
-        h, c = mlp_block_fwd(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps)
+        h, c = mlp_block_fwd(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps,
+                             allow_pad=True)
         ctx.c = c
         ctx.has = (gamma is not None, slope is not None)
         ctx.pids = (id(W), id(b) if b is not None else None)
+        # the output goes through save_for_backward: kept in ctx.c it would close a reference cycle (output ->
+        # grad_fn -> ctx -> output) that only the garbage collector frees, at a time of its choosing
+        c.h = None
+        ctx.save_for_backward(h)
         return h
 
     @staticmethod
@@ -281,7 +353,9 @@ class _MLPBlockFn(torch.autograd.Function):
             sW = cap.sink(ctx.pids[0])
             sb = cap.sink(ctx.pids[1]) if ctx.pids[1] is not None else None
             defer = cap.splitk if sW is not None else None
+        ctx.c.h, = ctx.saved_tensors
         r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0], dW_out=sW, db_out=sb, defer_reduce=defer)
+        ctx.c.h = None
         # gradients written into their sinks are not handed to autograd a second time
         return (r["dx"], None if sW is not None else r["dW"], None if sb is not None else r["db"], r["dgamma"], r["dbeta"],
                 r["dslope"], None, None, None, None, None, None)
@@ -289,6 +363,117 @@ class _MLPBlockFn(torch.autograd.Function):
 
 def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):
     return _MLPBlockFn.apply(x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps)
+
+
+_dropout_calls = 0
+
+
+class BlockSpec:
+    """What _MLPStackFn needs to know about one block besides its parameters."""
+    __slots__ = ("act", "norm", "training", "rm", "rv", "eps", "drop")
+
+    def __init__(self, act, norm, training, rm, rv, eps, drop):
+        self.act, self.norm, self.training, self.rm, self.rv, self.eps = act, norm, training, rm, rv, eps
+        self.drop = drop          # None or the (p, seed, salt, call_no, call_dev) key of the block's dropout mask
+
+
+class _MLPStackFn(torch.autograd.Function):
+    """A run of MLPBlocks (Layers.py:8-47) as one autograd node, so that the backward pass can do what the
+    block-by-block form cannot: a block's dx GEMM applies the previous block's act' in its epilogue and leaves the
+    partial column sums of the result (the previous block's bias gradient) behind, one launch finishes all of them,
+    and a 1-wide last block is a row-dot kernel whose backward emits dx and its weight gradient together."""
+
+    @staticmethod
+    def forward(ctx, x2d, specs, *params):
+        cs = []
+        h = x2d
+        for i, s in enumerate(specs):
+            W, b, gamma, beta, slope = params[5 * i:5 * i + 5]
+            h, c = mlp_block_fwd(h, W, b, s.act, s.norm, gamma, beta, slope, s.training, s.rm, s.rv, s.eps, allow_pad=True)
+            cs.append(c)
+            if s.drop is not None:
+                h = ops.dropout_apply(h, *s.drop)
+        ctx.cs, ctx.specs = cs, specs
+        ctx.pids = [id(p) if p is not None else None for p in params]
+        ctx.shapes = [(p.shape if p is not None else None) for p in params]
+        # the output goes through save_for_backward (kept in ctx.cs it would close a reference cycle output -> grad_fn
+        # -> ctx -> output that only the garbage collector frees)
+        ctx.out_is_h = h is cs[-1].h
+        if ctx.out_is_h:
+            cs[-1].h = None
+            ctx.save_for_backward(h)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        cs, specs = ctx.cs, ctx.specs
+        if ctx.out_is_h:
+            cs[-1].h, = ctx.saved_tensors
+        n = len(specs)
+        dev = dout.device
+        cap = TableCapture.active
+        sinks = cap is not None and bool(cap.grad_sinks)
+        grads = [None] * (5 * n)
+        dest = [None] * (5 * n)          # where the W / b gradient of a block is written
+        sunk = [False] * (5 * n)
+        for i in range(n):
+            for j in (0, 1):
+                k = 5 * i + j
+                if ctx.pids[k] is None:
+                    continue
+                t = cap.sink(ctx.pids[k]) if sinks else None
+                sunk[k] = t is not None
+                dest[k] = t if t is not None else torch.empty(ctx.shapes[k], dtype=torch.float32, device=dev)
+        parts = ops.ColsumParts(ops.default_workspace(dev))
+        dh = dout.contiguous()
+        dz_ready = db_done = False
+        for i in range(n - 1, -1, -1):
+            s, c = specs[i], cs[i]
+            if s.drop is not None:
+                dh = ops.dropout_apply(dh, *s.drop)          # what came in is the gradient of the masked output
+            prev = specs[i - 1] if i > 0 else None
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            fuse_prev = (prev is not None and not prev.norm and prev.act in (1, 2, 3) and prev.drop is None
+                         and dest[5 * (i - 1) + 1] is not None and c.x.shape[1] == c.k)
+            gW, gb = dest[5 * i], dest[5 * i + 1]
+            r = mlp_block_bwd(dh, c, need_dx=need_dx, dz_ready=dz_ready, dW_out=gW, db_out=gb,
+                              mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev.act if fuse_prev else 0,
+                              defer_reduce=cap.splitk if (sinks and sunk[5 * i]) else None,
+                              colsum_parts=parts if (fuse_prev or c.one) else None,
+                              dbp_out=dest[5 * (i - 1) + 1] if fuse_prev else None, db_done=db_done)
+            grads[5 * i + 2], grads[5 * i + 3], grads[5 * i + 4] = r["dgamma"], r["dbeta"], r["dslope"]
+            dh = r["dx"]
+            # the previous block's bias gradient is on its way if this block's dx launch left its partial sums
+            db_done = bool(r.get("dbp_left"))
+            dz_ready = fuse_prev
+        parts.finish()
+        if ctx.out_is_h:
+            cs[-1].h = None
+        for k in range(5 * n):
+            if dest[k] is not None and not sunk[k]:
+                grads[k] = dest[k]
+        return (dh, None, *grads)
+
+
+def mlp_stack(x2d, blocks):
+    """blocks: the MLPBlock modules of the run, in order."""
+    global _dropout_calls
+    cap = TableCapture.active
+    call_dev = getattr(cap, "rng_step", None) if cap is not None else None
+    specs, params = [], []
+    for b in blocks:
+        gamma, beta, rm, rv, eps = b._norm_args()
+        slope = b.activation_func.weight if b._act == ACT_CODES["prelu"] else None
+        drop = None
+        if b.dropout.p and b.training:
+            call_no = 0
+            if call_dev is None:
+                _dropout_calls += 1
+                call_no = _dropout_calls
+            drop = (float(b.dropout.p), torch.initial_seed(), int(b.dropout.salt), call_no, call_dev)
+        specs.append(BlockSpec(b._act, b.normalization or None, b.training, rm, rv, eps, drop))
+        params += [b.fc.weight, b.fc.bias, gamma, beta, slope]
+    return _MLPStackFn.apply(x2d, specs, *params)
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -306,9 +491,6 @@ class _DropoutFn(torch.autograd.Function):
         return ops.dropout_apply(g.contiguous(), p, seed, salt, call_no, call_dev), None, None, None, None, None
 
 
-_dropout_calls = 0
-
-
 def dropout(x, p: float, salt: int):
     """Training-mode dropout of x.  Inside a trainer's captured step the trainer's device step counter numbers the
     call (a replayed HIP graph draws a fresh mask every step); elsewhere a host-side call counter does."""
@@ -320,6 +502,33 @@ def dropout(x, p: float, salt: int):
         _dropout_calls += 1
         call_no = _dropout_calls
     return _DropoutFn.apply(x, float(p), torch.initial_seed(), int(salt), call_no, call_dev)
+
+
+class _BCEHeadFn(torch.autograd.Function):
+    """mean binary cross-entropy of sigmoid(z) against y -- torch.sigmoid + nn.BCELoss (model/LR/LR.py:32,
+    model/utils/BaseModel.py:74-77,145) -- with dL/dz from the same launch (torch's -100 clamp of the logarithms)."""
+
+    @staticmethod
+    def forward(ctx, z, y, assume_grad):
+        r = ops.bce_head([z.contiguous().view(-1)], y, want_dz=True,
+                         grad_scale=1.0 if assume_grad is None else float(assume_grad))
+        ctx.dz = r["dz"]
+        ctx.shape = z.shape
+        ctx.assumed = assume_grad is not None
+        return r["loss"].view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dz = ctx.dz if ctx.assumed else ctx.dz * g
+        return dz.view(ctx.shape), None, None
+
+
+def bce_of_logits(z, y, assume_grad=None):
+    """z: (B,) or (B, 1) logits; y: (B,) float32 or int64 labels.
+    assume_grad: the caller promises that the gradient arriving at the loss in backward() is this number (1.0 when
+    the loss itself is differentiated); dL/dz then leaves the forward launch already scaled and backward() adds no
+    launch of its own."""
+    return _BCEHeadFn.apply(z, y, assume_grad)
 
 
 class _AddFn(torch.autograd.Function):

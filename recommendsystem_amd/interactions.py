@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import functional as Fn
 from . import ops
 from ._lib import RSError
 from .layers import _StackedTables
@@ -60,18 +61,55 @@ def pnn_outer(emb: torch.Tensor) -> torch.Tensor:
 # -------------------------------------------------------------------------------------------------
 # DCN cross network
 # -------------------------------------------------------------------------------------------------
+def _end_to_end(ts) -> bool:
+    """The tensors lie one behind the other in one buffer (a trainer's flat parameter / gradient buffer)."""
+    p = ts[0].data_ptr()
+    for t in ts:
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.data_ptr() != p:
+            return False
+        p += t.numel() * 4
+    return True
+
+
+def _rows_view(ts, rows: int, width: int) -> torch.Tensor:
+    """[rows, width] over tensors that lie end to end (no copy), else their concatenation."""
+    if _end_to_end(ts):
+        return torch.as_strided(ts[0].detach().view(-1), (rows, width), (width, 1))
+    return torch.cat([t.detach().reshape(1, -1) for t in ts], 0)
+
+
 class _CrossFn(torch.autograd.Function):
+    """The L cross layers in one launch each way.  The 2L parameters come in one by one: inside a trainer they are
+    neighbouring views of its flat buffers, so w / b [L, D] are views (no concatenation launch) and the parameter
+    gradients land in the flat gradient buffer directly (no per-parameter accumulation launch)."""
+
     @staticmethod
-    def forward(ctx, x0, w, b):
-        x0, w, b = x0.contiguous(), w.contiguous(), b.contiguous()
+    def forward(ctx, x0, L, *params):
+        x0 = x0.contiguous()
+        D = x0.shape[1]
+        w, b = _rows_view(params[:L], L, D), _rows_view(params[L:], L, D)
         out, S = ops.dcn_cross_fwd(x0, w, b)
         ctx.save_for_backward(x0, w, b, S)
+        ctx.pids = [id(p) for p in params]
+        ctx.shapes = [p.shape for p in params]
         return out
 
     @staticmethod
     def backward(ctx, g):
         x0, w, b, S = ctx.saved_tensors
-        return ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b)
+        L, D = w.shape
+        cap = Fn.TableCapture.active
+        if cap is not None and cap.grad_sinks:
+            peek = [cap.grad_sinks.get(pid) for pid in ctx.pids]
+            if all(t is not None for t in peek) and not any(pid in cap._sunk for pid in ctx.pids) and _end_to_end(peek):
+                for pid in ctx.pids:
+                    cap.sink(pid)
+                g_out = torch.as_strided(peek[0].view(-1), (2 * L * D,), (1,))
+                dx0, _, _ = ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b, g_out=g_out)
+                return (dx0, None, *([None] * (2 * L)))
+        dx0, dW, dB = ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b)
+        grads = [dW[l].view(ctx.shapes[l]) for l in range(L)] + [dB[l].view(ctx.shapes[L + l]) for l in range(L)]
+        return (dx0, None, *grads)
 
 
 class CrossNetwork(nn.Module):
@@ -90,9 +128,7 @@ class CrossNetwork(nn.Module):
 
     def forward(self, x0):
         x0 = x0.reshape(x0.shape[0], -1)
-        w = torch.cat([p.view(1, -1) for p in self.cross_w], 0)
-        b = torch.cat([p.view(1, -1) for p in self.cross_b], 0)
-        return _CrossFn.apply(x0, w, b)
+        return _CrossFn.apply(x0, self.cross_layers_num, *self.cross_w, *self.cross_b)
 
 
 # -------------------------------------------------------------------------------------------------

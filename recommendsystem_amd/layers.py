@@ -278,6 +278,22 @@ class MLPBlock(nn.Module):
         return self.dropout(out)
 
 
+class MLPStack(nn.Sequential):
+    """nn.Sequential of MLPBlocks (what the reference's models build: model/DeepFM/DeepFM.py:25-38) whose forward hands
+    the whole run to one autograd node, so that its backward can fuse across block boundaries (functional._MLPStackFn).
+    Same children, same state_dict keys as the nn.Sequential; anything that is not a run of MLPBlocks on the GPU goes
+    block by block."""
+
+    def forward(self, x):
+        blocks = list(self)
+        if len(blocks) < 2 or not all(type(b) is MLPBlock for b in blocks) or not x.is_cuda:
+            return super().forward(x)
+        x = x.reshape(x.size()[0], -1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return Fn.mlp_stack(x, blocks)
+
+
 class ResidualMLPBlock(nn.Module):
     """Reference: model/utils/Layers.py:50-94.  identity (or downsample(x)) + block(x)."""
 

@@ -16,7 +16,7 @@ from torch import nn
 from . import functional as Fn
 from .base_model import BaseModel
 from . import interactions as X
-from .layers import Linear, LinearRegression_layer, MLPBlock, ResidualMLPBlock
+from .layers import Linear, LinearRegression_layer, MLPBlock, MLPStack, ResidualMLPBlock
 
 
 def _mlp_stack(input_dim, hidden_dim_list, activation_func, normalization, dropout_rate, head=True, block=MLPBlock):
@@ -30,7 +30,7 @@ def _mlp_stack(input_dim, hidden_dim_list, activation_func, normalization, dropo
         layers.append(block(hidden_dim_list[i], hidden_dim_list[i + 1], activation_func, normalization))
     if head:
         layers.append(block(hidden_dim_list[-1], 1, activation_func, normalization))
-    return nn.Sequential(*layers)
+    return MLPStack(*layers)
 
 
 class _CTRModel(BaseModel):

@@ -979,16 +979,17 @@ def dcn_cross_fwd(x0: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     return out, S
 
 
-def dcn_cross_bwd(x0, S, dout, w, bias):
-    """-> (dx0 [B,D], dW [L,D], dB [L,D])."""
+def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None):
+    """-> (dx0 [B,D], dW [L,D], dB [L,D]); g_out: optional [2*L*D] destination of (dW, dB) laid end to end."""
     B, D = x0.shape
     L = w.shape[0]
     _chk(dout, torch.float32, "dout", (B, D))
+    _chk(g_out, torch.float32, "g_out", (2 * L * D,))
     rows = interact_partial_rows(B)
     dx0 = torch.empty_like(x0)
     part = torch.empty((rows, 2 * L * D), dtype=torch.float32, device=x0.device)
     call("rs_dcn_cross_bwd", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx0), ptr(part), rows, stream())
-    g = colsum(part)
+    g = colsum(part, out=g_out)
     return dx0, g[:L * D].view(L, D), g[L * D:].view(L, D)
 
 

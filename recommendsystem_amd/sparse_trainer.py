@@ -83,6 +83,12 @@ class SparseTrainer:
         # scratch of this trainer's launches (split-K slabs, column-sum partials): private, so that a captured step
         # never shares a buffer with another model or with module-path calls on the same device
         self.ws = ops.Workspace(dev)
+        # Learned from the previous step: which plan sorts the batch a table is looked up with, and which tables share
+        # it.  The first lookup of such a group then sorts the batch and replays the skipped steps of every table of
+        # the group in one launch (the sort keeps only F workgroups busy) instead of a catch-up launch per table now
+        # and a sort launch in the backward pass.
+        self._group_of: Dict[int, dict] = {}
+        self._sorted: Dict[int, torch.Tensor] = {}      # per step: id(plan) -> the index matrix it has sorted
         self.check_every = 256           # steps between reads of the device-side error flags (a host synchronisation)
         self._unchecked = 0
 
@@ -141,8 +147,20 @@ class SparseTrainer:
         """A captured lookup is about to read `holder`'s table in a training step: replay the skipped steps of the
         rows it reads."""
         rs = self._table_state(holder)["rs"]
-        if rs is not None:
-            rs.catch_up(idx, holder.layout, 0)        # the update of this step stamps the rows it steps
+        if rs is None:
+            return
+        ent = self._group_of.get(id(holder))
+        if ent is not None and ent["B"] == idx.shape[1]:
+            plan = ent["plan"]
+            done = self._sorted.get(id(plan))
+            if done is idx:
+                return                                # caught up together with the sort of this batch
+            if done is None:
+                rs_of = lambda h: self._table_state(h)["rs"] if h is not None else None
+                plan.sort_and_catchup(idx, rs_of(ent["emb"]), rs_of(ent["lr"]))
+                self._sorted[id(plan)] = idx
+                return
+        rs.catch_up(idx, holder.layout, 0)            # the update of this step stamps the rows it steps
 
     def _plan(self, group, B):
         """One sort plan per group of lookups that share a batch (same index matrix and field vocabularies)."""
@@ -264,8 +282,17 @@ class SparseTrainer:
                         st["rs"].last.zero_()
         restore()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._graph_pool, stream=side), ops.use_workspace(self.ws):
-            loss = self._step_impl(x, labels)
+        # no cycle collection while the stream is capturing: a collected tensor from outside the graph's pool would
+        # make the allocator record events, which a capturing stream refuses
+        import gc
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, pool=self._graph_pool, stream=side), ops.use_workspace(self.ws):
+                loss = self._step_impl(x, labels)
+        finally:
+            if was_enabled:
+                gc.enable()
         if self._graph_pool is None:
             self._graph_pool = g.pool()
         torch.cuda.synchronize()
@@ -289,6 +316,7 @@ class SparseTrainer:
     def _forward_backward(self, inputs, y, provider=None, grad_scale: float = 1.0):
         """The model's forward and autograd backward with captured table lookups; dense gradients land in flat_g."""
         m = self.model
+        self._sorted.clear()
         self.flat_g_ext.zero_()
         for p, gv in zip(self.dense, self._gviews):
             p.grad = gv                              # autograd accumulates into the flat buffer in place
@@ -301,8 +329,13 @@ class SparseTrainer:
         with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk,
                              on_lookup=self._on_lookup if self.exact else None) as cap:
             cap.rng_step = self.step_count          # numbers the dropout masks: fresh ones at every (replayed) step
-            out = m.forward(inputs)
-            loss = m.criterion(out.squeeze(1), y.float())
+            if hasattr(m, "logits") and m.criterion is torch.nn.functional.binary_cross_entropy:
+                # sigmoid + BCE + dL/dlogit in one launch instead of torch's five
+                yl = y if y.dtype in (torch.float32, torch.int64) else y.float()
+                loss = Fn.bce_of_logits(m.logits(inputs), yl.contiguous(), assume_grad=grad_scale)
+            else:
+                out = m.forward(inputs)
+                loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
                 loss = loss + m.regularization_loss()
             (loss if grad_scale == 1.0 else loss * grad_scale).backward()
@@ -339,7 +372,13 @@ class SparseTrainer:
                 else:
                     P[off + nw:off + n].zero_()
             else:
-                plan.sort_columnar(idx)
+                if self._sorted.get(id(plan)) is not idx:
+                    plan.sort_columnar(idx)
+                if self.exact:
+                    for r in group.values():
+                        self._group_of[id(r["holder"])] = {
+                            "plan": plan, "B": B, "emb": group["emb"]["holder"] if "emb" in group else None,
+                            "lr": group["lr"]["holder"] if "lr" in group else None}
                 ge, gl = grad("emb"), grad("lr")
                 plan.reduce(P[off:off + n], gout=ge.view(B * plan.F, plan.d) if ge is not None else None,
                             dlr=gl.view(B) if gl is not None else None)

@@ -115,13 +115,24 @@ def test_dcn_cross(B, D, L):
     ref = O.dcn_cross(xr, [wr[l] for l in range(L)], [br[l] for l in range(L)])
     gout = torch.randn(B, D, generator=g)
     ref.backward(gout)
-    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x0, w, b))
-    out = _CrossFn.apply(xg, wg, bg)
-    close(out, ref, rtol=2e-5, atol=2e-6, msg="fwd")
-    out.backward(gout.to(DEV))
-    close(xg.grad, xr.grad, rtol=5e-5, atol=5e-6, msg="dx0")
-    close(wg.grad, wr.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="dw")
-    close(bg.grad, br.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="db")
+    xg = x0.to(DEV).requires_grad_(True)
+    # the 2L parameters one by one, as the module holds them: (D, 1) each; once as separate tensors, once as
+    # neighbouring views of one buffer (what a trainer's flat parameter buffer gives: no concatenation)
+    for flat in (False, True):
+        if flat:
+            buf = torch.cat([w.reshape(-1), b.reshape(-1)]).to(DEV)
+            ps = [buf[i * D:(i + 1) * D].view(D, 1).requires_grad_(True) for i in range(2 * L)]
+        else:
+            ps = [t.to(DEV).clone().view(D, 1).requires_grad_(True) for t in list(w) + list(b)]
+        xg.grad = None
+        out = _CrossFn.apply(xg, L, *ps)
+        close(out, ref, rtol=2e-5, atol=2e-6, msg="fwd")
+        out.backward(gout.to(DEV))
+        close(xg.grad, xr.grad, rtol=5e-5, atol=5e-6, msg="dx0")
+        wgrad = torch.stack([p.grad.view(-1) for p in ps[:L]])
+        bgrad = torch.stack([p.grad.view(-1) for p in ps[L:]])
+        close(wgrad, wr.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="dw")
+        close(bgrad, br.grad, rtol=5e-5, atol=2e-5 * max(1.0, B ** 0.5 / 8), msg="db")
 
 
 def test_dcn_module_reference_shapes():

@@ -97,3 +97,89 @@ def test_residual_block_against_oracle_at_model_widths(B, i, o, act, norm):
         torch.testing.assert_close(v.grad.cpu(), rp[k].grad, rtol=1e-4, atol=2e-5 * scale, msg=lambda s, k=k: f"d{k}: {s}")
     torch.testing.assert_close(blk.norm_layer.running_mean.cpu(), ref.norm_layer.running_mean, rtol=1e-5, atol=1e-6) \
         if norm == "bn" else None
+
+
+def _oracle_stack(blocks, x, g):
+    """The same run of blocks on the CPU oracle (oracle/ctr_oracle.py OracleMLPBlock = Layers.py:8-47, dropout 0)."""
+    from oracle import ctr_oracle as O
+    act_name = {1: "relu", 2: "tanh", 3: "leakyrelu", 4: "prelu"}
+    obs = []
+    for b in blocks:
+        ob = O.OracleMLPBlock(b.fc.in_features, b.fc.out_features, act_name[b._act], b.normalization or None)
+        ob.load_state_dict({k.replace("activation_func.", "prelu."): v.detach().cpu() for k, v in b.state_dict().items()})
+        obs.append(ob.train())
+    xo = x.detach().cpu().requires_grad_(True)
+    h = xo
+    for ob in obs:
+        h = ob(h)
+    (h * g.cpu()).sum().backward()
+    return h.detach(), xo.grad, obs
+
+
+@pytest.mark.parametrize("spec", [
+    [(40, 24, "relu", None), (24, 12, "tanh", None), (12, 1, "relu", None)],            # all fused, 1-wide head
+    [(40, 24, "leakyrelu", None), (24, 12, "relu", "bn"), (12, 8, "tanh", None)],         # a normalised block in the middle
+    [(40, 24, "prelu", None), (24, 12, "relu", "ln"), (12, 1, "tanh", None)],             # PReLU cannot ride in an epilogue
+    [(1365, 64, "relu", None), (64, 1, "relu", None)],                                     # odd input width: padded to 1368
+], ids=["plain-head", "bn-middle", "prelu-ln-head", "odd-width"])
+def test_mlp_stack_matches_oracle_and_block_by_block(spec):
+    """layers.MLPStack (one autograd node, fused backward) against the CPU oracle's blocks and against the same
+    modules run one by one."""
+    from torch import nn
+    from recommendsystem_amd import layers
+    torch.manual_seed(3)
+    blocks = [layers.MLPBlock(i, o, a, n) for i, o, a, n in spec]
+    stack = layers.MLPStack(*blocks).cuda().train()
+    B = 512
+    x = torch.randn(B, spec[0][0], device="cuda").requires_grad_(True)
+    g = torch.randn(B, spec[-1][1], device="cuda")
+    want_y, want_dx, obs = _oracle_stack(blocks, x, g)
+    y = stack(x)
+    scale = max(1.0, float(want_y.abs().max()))
+    torch.testing.assert_close(y.detach().cpu(), want_y, rtol=2e-5, atol=5e-6 * scale)
+    (y * g).sum().backward()
+    torch.testing.assert_close(x.grad.cpu(), want_dx, rtol=2e-5, atol=5e-6 * max(1.0, float(want_dx.abs().max())))
+    for b, ob in zip(blocks, obs):
+        oq = dict(ob.named_parameters())
+        for k, p in b.named_parameters():
+            q = oq[k.replace("activation_func.", "prelu.")]
+            atol = 1e-5 * max(1.0, float(q.grad.abs().max()))
+            if k == "fc.bias" and b.normalization:
+                # a bias in front of a normalisation has gradient zero: both sides hold the rounding of a 512-term sum
+                atol = 1e-4
+            torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=2e-5, atol=atol, msg=lambda s, k=k: f"d{k}: {s}")
+    # block by block (nn.Sequential's own forward): same forward bits
+    fused = {k: p.grad.clone() for k, p in stack.named_parameters()}
+    dx_fused = x.grad.clone()
+    for p in stack.parameters():
+        p.grad = None
+    x.grad = None
+    # (BatchNorm running statistics were advanced once: irrelevant to the train-mode output)
+    y2 = nn.Sequential.forward(stack, x)
+    assert torch.equal(y2, y)
+    (y2 * g).sum().backward()
+    torch.testing.assert_close(x.grad, dx_fused, rtol=1e-5, atol=1e-6 * max(1.0, float(dx_fused.abs().max())))
+    for k, p in stack.named_parameters():
+        atol = 1e-4 if k.endswith("fc.bias") and blocks[int(k.split(".")[0])].normalization else \
+            2e-6 * max(1.0, float(fused[k].abs().max()))
+        torch.testing.assert_close(p.grad, fused[k], rtol=1e-5, atol=atol, msg=lambda s, k=k: f"d{k}: {s}")
+
+
+def test_bce_of_logits_matches_torch():
+    """functional.bce_of_logits = torch.sigmoid + F.binary_cross_entropy (mean), value and gradient, including
+    saturated logits (torch clamps the logarithms at -100)."""
+    from recommendsystem_amd import functional as Fn
+    torch.manual_seed(0)
+    z = (torch.randn(4096) * 4).tolist()
+    z[:4] = [60.0, -60.0, 120.0, -120.0]
+    z = torch.tensor(z)
+    y = (torch.rand(4096) < 0.3).float()
+    zc = z.clone().requires_grad_(True)
+    want = torch.nn.functional.binary_cross_entropy(torch.sigmoid(zc), y)
+    want.backward()
+    for assume in (None, 1.0):
+        zg = z.cuda().requires_grad_(True)
+        got = Fn.bce_of_logits(zg.view(-1, 1), y.cuda(), assume_grad=assume)
+        got.backward()
+        torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(zg.grad.cpu(), zc.grad, rtol=1e-5, atol=1e-9)

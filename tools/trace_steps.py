@@ -1,5 +1,10 @@
 """Per-step kernel breakdown from a rocprofv3 kernel trace of bench.py: steps are delimited by the fused gather
-launch (alone or sharing its launch with the index sort); the fastest `--keep` steps (the graph replays of the timed region) are averaged."""
+launch (alone or sharing its launch with the index sort) or, with a third argument, by the kernel whose name contains
+it (one launch per step, e.g. field_sort_kernel for the generic trainer); the fastest `keep` steps (the graph replays
+of the timed region) are averaged.
+
+    python tools/trace_steps.py <kernel_trace.csv> [keep] [marker]
+"""
 import csv
 import sys
 from collections import defaultdict
@@ -11,7 +16,9 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "gather_fused_kernel" in r[2] or "sort_gather_kernel" in r[2]]
+marker = sys.argv[3] if len(sys.argv) > 3 else None
+starts = [i for i, r in enumerate(rows)
+          if (marker in r[2] if marker else ("gather_fused_kernel" in r[2] or "sort_gather_kernel" in r[2]))]
 steps = []
 for a, b in zip(starts, starts[1:]):
     steps.append((rows[b][0] - rows[a][0], a, b))
