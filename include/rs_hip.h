@@ -73,6 +73,13 @@ int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out /* host pointer *
 int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
                 float* workspace, size_t workspace_bytes, float* colsum_part, rs_stream_t stream);
+/* C = act(C + op(A) op(B) + bias): one term of a product whose reduction dimension is walked in several calls, so that
+ * the whole left operand never has to exist at once -- the first MLP layer of PNN over the outer products of all field
+ * pairs (model/PNN/PNN.py:19-27,58,80-103: 741 * 256 inputs per sample at F = 39, d = 16), evaluated a block of pairs at
+ * a time.  bias and act belong to the last call. */
+int rs_gemm_f32_acc(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                    int ldc, const float* bias, int act, int tile, int splitk, float* workspace, size_t workspace_bytes,
+                    rs_stream_t stream);
 /* A split product without its reducing launch: the splitk slabs [splitk, M, N] stay in `workspace` until
  * rs_splitk_reduce_multi adds them, in slab order, into contiguous [M, N] outputs for up to 8 such products in one
  * launch (host arrays of device pointers / element counts / split counts).  Used for the weight gradients of a
@@ -178,6 +185,13 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
 /* PNN outer products e_i e_j^T flattened -> out[B,P*d*d]         (model/PNN/PNN.py:80-103) */
 int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, rs_stream_t stream);
 int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, rs_stream_t stream);
+/* The same for the pairs (i, j) with i in [i_lo, i_hi) only (pairs are numbered first field major, PNN.py:83-85): out /
+ * dout hold those pairs, (p_hi - p_lo)*d*d columns with row stride ld; with accumulate the backward adds to demb.  Lets
+ * the first MLP layer over the products (PNN.py:19-27,58) run a block of pairs at a time (rs_gemm_f32_acc). */
+int rs_pnn_outer_fwd_range(const float* emb, int B, int F, int d, int i_lo, int i_hi, float* out, long long ld,
+                           rs_stream_t stream);
+int rs_pnn_outer_bwd_range(const float* emb, const float* dout, long long ld, int B, int F, int d, int i_lo, int i_hi,
+                           int accumulate, float* demb, rs_stream_t stream);
 
 /* DCN cross network x_{l+1} = x0 (x_l . w_l) + b_l + x_l, w/bias [L,D]; S[B,L] = x_l . w_l saved for the backward
  * (model/DCN/DCN.py:48-52, with the bias broadcast over the batch).  partials: [rows, 2*L*D] = [dW | dB]. */

@@ -31,6 +31,7 @@ _SIGS = {
     # gemm.hip
     "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
                     I, I, c_f32p, SZ, c_f32p, c_stream],
+    "rs_gemm_f32_acc": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
     "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, SZ, c_stream],
     "rs_colsum_f32_noalloc": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_gemm_f32_slabs": [I, I, I, I, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
@@ -99,6 +100,8 @@ _SIGS = {
     "rs_pnn_inner_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_outer_fwd_range": [c_f32p, I, I, I, I, I, c_f32p, L, c_stream],
+    "rs_pnn_outer_bwd_range": [c_f32p, c_f32p, L, I, I, I, I, I, I, c_f32p, c_stream],
     "rs_dcn_cross_fwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_dcn_cross_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
     "rs_nfm_bi_fwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],

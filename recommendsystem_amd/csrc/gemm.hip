@@ -50,6 +50,7 @@ struct GemmArgs {
                             // 1 = no DMA in the k loop, 2 = no stores, 4 = no MFMA, 8 = no barrier in the k loop,
                             // 16 = no LDS fragment reads after the first k-tile
     int defer;              // splitk > 1: leave the slabs in ws, the caller reduces them later (rs_splitk_reduce_multi)
+    int accum;              // add what C holds to the product before bias and activation (a sum built up over several calls)
 };
 #ifdef RS_GEMM_EXPERIMENT
 #define RS_DBG(g) ((g).dbg)
@@ -67,6 +68,7 @@ __device__ __forceinline__ float act_grad_from_h(int act, float h) {
 }
 
 __device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int n) {
+    if (g.accum) v += g.C[(long long)m * g.ldc + n];
     if (g.bias) v += g.bias[n];
     v = rs_act(g.act, v, 0.f);
     if (g.mulsrc) v *= act_grad_from_h(g.mul_act, g.mulsrc[(long long)m * g.ldm + n]);
@@ -461,6 +463,10 @@ __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM 
         if (m < g.M && n < g.N) {
             float4 v = *reinterpret_cast<const float4*>(smem + row * LDT + c4);
             if (!partial) {
+                if (g.accum) {
+                    const float4 o = *reinterpret_cast<const float4*>(out + (long long)m * ldo + n);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
                 v.x = rs_act(g.act, v.x + bv.x, 0.f); v.y = rs_act(g.act, v.y + bv.y, 0.f);
                 v.z = rs_act(g.act, v.z + bv.z, 0.f); v.w = rs_act(g.act, v.w + bv.w, 0.f);
                 if (g.mulsrc) {
@@ -876,7 +882,7 @@ int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile 
 static int gemm_impl(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
                      int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part, int defer,
-                     hipStream_t stream) {
+                     int accum, hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "rs_gemm_f32: negative size");
     if (M == 0 || N == 0) return RS_OK;
     RS_CHECK_ARG(A && B && C, "rs_gemm_f32: null operand");
@@ -906,7 +912,7 @@ static int gemm_impl(int a_mc, int b_nc, int M, int N, int K, const float* A, in
     const bool vec_epi = allow_vec && N % 4 == 0 && aligned16(C) && ldc % 4 == 0 && (!bias || aligned16(bias)) &&
                          (!mulsrc || (aligned16(mulsrc) && ldm % 4 == 0)) && (splitk == 1 || aligned16(workspace));
     GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part,
-               vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg, defer};
+               vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg, defer, accum};
     RS_CHECK_ARG(!defer || splitk > 1, "rs_gemm_f32_slabs: the reduction did not split (splitk resolved to %d)", splitk);
     g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
@@ -924,7 +930,16 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
                 int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part,
                 hipStream_t stream) {
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mulsrc, ldm, mul_act, tile, splitk, workspace,
-                     workspace_bytes, colsum_part, 0, stream);
+                     workspace_bytes, colsum_part, 0, 0, stream);
+}
+
+// C = act(C + op(A) op(B) + bias): one term of a product whose reduction dimension is walked in several calls (the
+// operands of a later term may then reuse the buffers of an earlier one); bias and activation belong to the last call.
+int rs_gemm_f32_acc(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                    int ldc, const float* bias, int act, int tile, int splitk, float* workspace, size_t workspace_bytes,
+                    hipStream_t stream) {
+    return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, 0, tile, splitk, workspace,
+                     workspace_bytes, nullptr, 0, 1, stream);
 }
 
 // The split-K product without its reducing launch: the splitk slabs [splitk, M, N] stay in `workspace` (which must
@@ -935,7 +950,7 @@ int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, i
     RS_CHECK_ARG(tile >= 0 && splitk > 1 && workspace, "rs_gemm_f32_slabs: needs an explicit tile, splitk > 1 and a workspace");
     RS_CHECK_ARG(splitk <= rs_cdiv(K, BK), "rs_gemm_f32_slabs: splitk %d exceeds the k-tiles of K=%d", splitk, K);
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, workspace, N, nullptr, RS_ACT_NONE, nullptr, 0, 0, tile, splitk,
-                     workspace, workspace_bytes, nullptr, 1, stream);
+                     workspace, workspace_bytes, nullptr, 1, 0, stream);
 }
 
 // C[p][e] = sum_z ws[p][z * total[p] + e], z < splitk[p] in slab order, e < total[p], for p < count (<= 8) products in

@@ -235,9 +235,12 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
 // ---- PNN outer product (model/PNN/PNN.py:80-103) --------------------------------------------------
 // out[b, p, a, c] = e_i[a] * e_j[c] for pair p = (i, j).  One workgroup per sample, the (i, j) table of
 // all pairs in LDS; the kernel is bound by the HBM write of P*d*d floats per sample.
+// The kernels take a range of pairs [p_lo, p_hi) (a range of first fields: pairs are numbered first field major) and the
+// row stride of out / dout, whose column 0 is pair p_lo: the first MLP layer over the products can then be evaluated a
+// block of pairs at a time without the whole (B, P*d*d) matrix ever existing.
 template <int VEC>
 __global__ __launch_bounds__(256) void pnn_outer_fwd_kernel(const float* __restrict__ emb, int B, int F, int d,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int p_lo, int p_hi, long long ld) {
     extern __shared__ float sm[];
     const int fd = F * d, P = F * (F - 1) / 2, dd = d * d;
     float* e = sm;
@@ -251,13 +254,13 @@ __global__ __launch_bounds__(256) void pnn_outer_fwd_kernel(const float* __restr
         tab[p] = i | (j << 16);
     }
     __syncthreads();
-    float* o = out + (long long)b * P * dd;
-    const int total = P * dd / VEC;
+    float* o = out + (long long)b * ld;
+    const int total = (p_hi - p_lo) * dd / VEC;
     for (int q = threadIdx.x; q < total; q += 256) {
         const int x = q * VEC;
-        const int p = x / dd, r = x - p * dd;
+        const int pl = x / dd, r = x - pl * dd;
         const int a = r / d, c = r - a * d;
-        const int ij = tab[p], i = ij & 0xffff, j = ij >> 16;
+        const int ij = tab[p_lo + pl], i = ij & 0xffff, j = ij >> 16;
         const float ea = e[i * d + a];
         if constexpr (VEC == 4) {
             const float4 ej = *reinterpret_cast<const float4*>(e + j * d + c);
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void pnn_outer_fwd_kernel(const float* __restr
 
 // d = 16: index arithmetic by shifts; a wave writes one whole 16x16 block (1 KB contiguous) per step.
 __global__ __launch_bounds__(256) void pnn_outer_fwd16_kernel(const float* __restrict__ emb, int B, int F,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int p_lo, int p_hi, long long ld) {
     extern __shared__ float sm[];
     const int fd = F * 16, P = F * (F - 1) / 2;
     float* e = sm;
@@ -284,11 +287,11 @@ __global__ __launch_bounds__(256) void pnn_outer_fwd16_kernel(const float* __res
         tab[p] = i | (j << 16);
     }
     __syncthreads();
-    float4* o = reinterpret_cast<float4*>(out + (long long)b * P * 256);
-    const int total = P * 64;
+    float4* o = reinterpret_cast<float4*>(out + (long long)b * ld);
+    const int total = (p_hi - p_lo) * 64;
 #pragma unroll 4
     for (int q = threadIdx.x; q < total; q += 256) {
-        const int p = q >> 6, a = (q >> 2) & 15, c4 = q & 3;
+        const int p = p_lo + (q >> 6), a = (q >> 2) & 15, c4 = q & 3;
         const int ij = tab[p], i = ij & 0xffff, j = ij >> 16;
         const float ea = e[i * 16 + a];
         const float4 ej = *reinterpret_cast<const float4*>(e + j * 16 + 4 * c4);
@@ -298,27 +301,31 @@ __global__ __launch_bounds__(256) void pnn_outer_fwd16_kernel(const float* __res
 
 // demb[b,f,k] = sum_{j>f} sum_c dO[p(f,j), k, c] e_j[c] + sum_{i<f} sum_a dO[p(i,f), a, k] e_i[a]
 __global__ __launch_bounds__(256) void pnn_outer_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                            int B, int F, int d, float* __restrict__ demb) {
+                                                            int B, int F, int d, float* __restrict__ demb, int i_lo, int i_hi,
+                                                            long long ld, int accumulate) {
     extern __shared__ float sm[];
-    const int fd = F * d, P = F * (F - 1) / 2, dd = d * d;
+    const int fd = F * d, dd = d * d;
+    const int p_lo = pair_start(i_lo, F);
     float* e = sm;
     const int b = blockIdx.x;
     const float* src = emb + (long long)b * fd;
     for (int i = threadIdx.x; i < fd; i += 256) e[i] = src[i];
     __syncthreads();
-    const float* g = dout + (long long)b * P * dd;
+    const float* g = dout + (long long)b * ld - (long long)p_lo * dd;
     for (int idx = threadIdx.x; idx < fd; idx += 256) {
         const int f = idx / d, k = idx - f * d;
         float acc = 0.f;
-        for (int j = f + 1; j < F; ++j) {
-            const float* row = g + (long long)pair_index(f, j, F) * dd + k * d;
-            for (int c = 0; c < d; ++c) acc = fmaf(row[c], e[j * d + c], acc);
-        }
-        for (int i = 0; i < f; ++i) {
+        if (f >= i_lo && f < i_hi)
+            for (int j = f + 1; j < F; ++j) {
+                const float* row = g + (long long)pair_index(f, j, F) * dd + k * d;
+                for (int c = 0; c < d; ++c) acc = fmaf(row[c], e[j * d + c], acc);
+            }
+        for (int i = i_lo; i < min(f, i_hi); ++i) {
             const float* col = g + (long long)pair_index(i, f, F) * dd + k;
             for (int a = 0; a < d; ++a) acc = fmaf(col[a * d], e[i * d + a], acc);
         }
-        demb[(long long)b * fd + idx] = acc;
+        float* dst = demb + (long long)b * fd + idx;
+        *dst = accumulate ? *dst + acc : acc;
     }
 }
 
@@ -328,9 +335,10 @@ __global__ __launch_bounds__(256) void pnn_outer_bwd_kernel(const float* __restr
 // column sums (for e_j) are reduced over ta with two shuffle steps and added to the wave's own LDS accumulator.
 // The four waves of the workgroup (rows i = wave, wave + 4, ...) are combined in fixed order at the end.
 __global__ __launch_bounds__(256) void pnn_outer_bwd16_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                              int B, int F, float* __restrict__ demb) {
+                                                              int B, int F, float* __restrict__ demb, int i_lo, int i_hi,
+                                                              long long ld, int accumulate) {
     extern __shared__ float sm[];
-    const int fd = F * 16, P = F * (F - 1) / 2;
+    const int fd = F * 16;
     float* e = sm;                    // [F*16]
     float* rowres = e + fd;           // [F*16]
     float* colacc = rowres + fd;      // [4][F*16]
@@ -341,9 +349,9 @@ __global__ __launch_bounds__(256) void pnn_outer_bwd16_kernel(const float* __res
     for (int i = threadIdx.x; i < 4 * fd; i += 256) colacc[i] = 0.f;
     __syncthreads();
     const int tc = lane & 3, ta = (lane >> 2) & 3, gq = lane >> 4;
-    const float* gbase = dout + (long long)b * P * 256;
+    const float* gbase = dout + (long long)b * ld - (long long)pair_start(i_lo, F) * 256;
     float* myc = colacc + wv * fd;
-    for (int i = wv; i < F - 1; i += 4) {
+    for (int i = i_lo + wv; i < min(i_hi, F - 1); i += 4) {
         float ei[4], racc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ei[r] = e[i * 16 + 4 * ta + r]; racc[r] = 0.f; }
@@ -390,8 +398,11 @@ __global__ __launch_bounds__(256) void pnn_outer_bwd16_kernel(const float* __res
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < fd; i += 256)
-        demb[(long long)b * fd + i] = rowres[i] + (((colacc[i] + colacc[fd + i]) + colacc[2 * fd + i]) + colacc[3 * fd + i]);
+    for (int i = threadIdx.x; i < fd; i += 256) {
+        const float t = rowres[i] + (((colacc[i] + colacc[fd + i]) + colacc[2 * fd + i]) + colacc[3 * fd + i]);
+        float* dst = demb + (long long)b * fd + i;
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 // ---- DCN cross network (model/DCN/DCN.py:48-52 in its intended (B, D) shape) -----------------------
@@ -1706,37 +1717,68 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
 }
 
 // PNN outer products: emb [B,F,d] -> out [B, P*d*d] (model/PNN/PNN.py:80-103).
-int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, hipStream_t stream) {
-    RS_CHECK_ARG(B >= 0 && F > 1 && F < 32768 && d > 0, "rs_pnn_outer_fwd: bad sizes");
+// The *_range forms serve the pairs whose first field lies in [i_lo, i_hi): out / dout hold those pairs only, row stride
+// ld floats; the backward adds its result to demb when accumulate is set.
+static int pnn_outer_fwd_impl(const float* emb, int B, int F, int d, int i_lo, int i_hi, float* out, long long ld,
+                              hipStream_t stream, const char* who) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && F < 32768 && d > 0, "%s: bad sizes", who);
+    RS_CHECK_ARG(0 <= i_lo && i_lo < i_hi && i_hi <= F, "%s: bad field range [%d, %d)", who, i_lo, i_hi);
     if (B == 0) return RS_OK;
-    RS_CHECK_ARG(emb && out, "rs_pnn_outer_fwd: null argument");
+    RS_CHECK_ARG(emb && out, "%s: null argument", who);
     const int P = F * (F - 1) / 2;
-    RS_CHECK_ARG((long long)P * d * d < (1ll << 31), "rs_pnn_outer_fwd: output row too long");
+    const int p_lo = i_lo * (2 * F - i_lo - 1) / 2, p_hi = i_hi >= F - 1 ? P : i_hi * (2 * F - i_hi - 1) / 2;
+    if (p_hi == p_lo) return RS_OK;
+    RS_CHECK_ARG((long long)(p_hi - p_lo) * d * d < (1ll << 31) && ld >= (long long)(p_hi - p_lo) * d * d,
+                 "%s: output row too long or row stride too small", who);
     const size_t lds = (size_t)(F * d + P) * sizeof(float);
-    RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_outer_fwd: F=%d d=%d does not fit the LDS staging", F, d);
-    if (d == 16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
-        hipLaunchKernelGGL(pnn_outer_fwd16_kernel, dim3(B), dim3(256), lds, stream, emb, B, F, out);
-    else if (d % 4 == 0) hipLaunchKernelGGL(pnn_outer_fwd_kernel<4>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out);
-    else hipLaunchKernelGGL(pnn_outer_fwd_kernel<1>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out);
-    RS_CHECK_LAUNCH("rs_pnn_outer_fwd");
+    RS_CHECK_ARG(lds <= LDS_LIMIT, "%s: F=%d d=%d does not fit the LDS staging", who, F, d);
+    if (d == 16 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ld % 4 == 0)
+        hipLaunchKernelGGL(pnn_outer_fwd16_kernel, dim3(B), dim3(256), lds, stream, emb, B, F, out, p_lo, p_hi, ld);
+    else if (d % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ld % 4 == 0)
+        hipLaunchKernelGGL(pnn_outer_fwd_kernel<4>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out, p_lo, p_hi, ld);
+    else hipLaunchKernelGGL(pnn_outer_fwd_kernel<1>, dim3(B), dim3(256), lds, stream, emb, B, F, d, out, p_lo, p_hi, ld);
+    RS_CHECK_LAUNCH(who);
     return RS_OK;
 }
 
-int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, hipStream_t stream) {
-    RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_outer_bwd: bad sizes");
+static int pnn_outer_bwd_impl(const float* emb, const float* dout, long long ld, int B, int F, int d, int i_lo, int i_hi,
+                              int accumulate, float* demb, hipStream_t stream, const char* who) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "%s: bad sizes", who);
+    RS_CHECK_ARG(0 <= i_lo && i_lo < i_hi && i_hi <= F, "%s: bad field range [%d, %d)", who, i_lo, i_hi);
     if (B == 0) return RS_OK;
-    RS_CHECK_ARG(emb && dout && demb, "rs_pnn_outer_bwd: null argument");
-    if (d == 16 && (size_t)6 * F * 16 * sizeof(float) <= LDS_LIMIT && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) {
+    RS_CHECK_ARG(emb && dout && demb, "%s: null argument", who);
+    if (d == 16 && (size_t)6 * F * 16 * sizeof(float) <= LDS_LIMIT && (reinterpret_cast<uintptr_t>(dout) & 15) == 0 &&
+        ld % 4 == 0) {
         hipLaunchKernelGGL(pnn_outer_bwd16_kernel, dim3(B), dim3(256), (size_t)6 * F * 16 * sizeof(float), stream, emb, dout, B,
-                           F, demb);
-        RS_CHECK_LAUNCH("rs_pnn_outer_bwd");
+                           F, demb, i_lo, i_hi, ld, accumulate);
+        RS_CHECK_LAUNCH(who);
         return RS_OK;
     }
     const size_t lds = (size_t)F * d * sizeof(float);
-    RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_outer_bwd: F*d=%d does not fit the LDS staging", F * d);
-    hipLaunchKernelGGL(pnn_outer_bwd_kernel, dim3(B), dim3(256), lds, stream, emb, dout, B, F, d, demb);
-    RS_CHECK_LAUNCH("rs_pnn_outer_bwd");
+    RS_CHECK_ARG(lds <= LDS_LIMIT, "%s: F*d=%d does not fit the LDS staging", who, F * d);
+    hipLaunchKernelGGL(pnn_outer_bwd_kernel, dim3(B), dim3(256), lds, stream, emb, dout, B, F, d, demb, i_lo, i_hi, ld,
+                       accumulate);
+    RS_CHECK_LAUNCH(who);
     return RS_OK;
+}
+
+int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, hipStream_t stream) {
+    return pnn_outer_fwd_impl(emb, B, F, d, 0, F, out, (long long)(F * (F - 1) / 2) * d * d, stream, "rs_pnn_outer_fwd");
+}
+
+int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, hipStream_t stream) {
+    return pnn_outer_bwd_impl(emb, dout, (long long)(F * (F - 1) / 2) * d * d, B, F, d, 0, F, 0, demb, stream,
+                              "rs_pnn_outer_bwd");
+}
+
+int rs_pnn_outer_fwd_range(const float* emb, int B, int F, int d, int i_lo, int i_hi, float* out, long long ld,
+                           hipStream_t stream) {
+    return pnn_outer_fwd_impl(emb, B, F, d, i_lo, i_hi, out, ld, stream, "rs_pnn_outer_fwd_range");
+}
+
+int rs_pnn_outer_bwd_range(const float* emb, const float* dout, long long ld, int B, int F, int d, int i_lo, int i_hi,
+                           int accumulate, float* demb, hipStream_t stream) {
+    return pnn_outer_bwd_impl(emb, dout, ld, B, F, d, i_lo, i_hi, accumulate, demb, stream, "rs_pnn_outer_bwd_range");
 }
 
 // DCN cross network, L layers: x0 [B,D], w [L,D], bias [L,D] -> out [B,D]; S [B,L] (x_l . w_l) is saved

@@ -201,7 +201,8 @@ def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
 # MLP blocks
 # -------------------------------------------------------------------------------------------------
 class MLPCtx:
-    __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps", "k", "one")
+    __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps", "k", "one",
+                 "linear")
 
 
 def _pad_columns(t, pad: int):
@@ -213,14 +214,40 @@ def _pad_columns(t, pad: int):
 
 
 def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=None, slope=None, training=True,
-                  running_mean=None, running_var=None, eps=1e-5, allow_pad=False):
+                  running_mean=None, running_var=None, eps=1e-5, allow_pad=False, linear=None):
     """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx).
 
-    allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width)."""
+    allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width).
+    linear: an object whose forward() returns x W^T + b and whose backward(dz) returns dict(dx, dW, db) in place of the
+    plain GEMMs (OuterLinear: an input too wide to exist at once); x2d is then ignored."""
     c = MLPCtx()
     c.x, c.W, c.act, c.norm, c.gamma, c.slope, c.eps = x2d, W, act, norm, gamma, slope, eps
     c.z = c.y = c.xhat = c.var = c.rstd = None
     c.k = W.shape[1]
+    c.linear = linear
+    if linear is not None:
+        c.one = False
+        z = linear.forward()
+        fus = act if act in _FUSABLE else 0
+        if not norm:
+            if act in _FUSABLE:
+                c.h = ops.act_fwd(z, act) if act else z
+            else:
+                c.z = z
+                c.h = ops.act_fwd(z, act, slope)
+            return c.h, c
+        if norm == "bn":
+            y, c.xhat, c.var = ops.bn_fwd(z, gamma, beta, fus, training, running_mean, running_var, eps)
+        elif norm == "ln":
+            y, c.xhat, c.rstd = ops.ln_fwd(z, gamma, beta, fus, eps)
+        else:
+            raise ValueError("normalization must be either 'bn' or 'ln' or None")
+        if act in _FUSABLE:
+            c.h = y
+        else:
+            c.y = y
+            c.h = ops.act_fwd(y, act, slope)
+        return c.h, c
     # a 1-wide plain layer is a dot product per row, not a GEMM
     c.one = (W.shape[0] == 1 and not norm and act in _FUSABLE and b is not None and W.shape[1] <= _ONE_WIDE_MAX_K
              and (W.shape[1] % 4 != 0 or (x2d.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)))
@@ -284,6 +311,11 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             dz, out["dgamma"], out["dbeta"] = ops.bn_bwd(dh, hh, c.xhat, fus, c.gamma, c.var, c.eps)
         else:
             dz, out["dgamma"], out["dbeta"] = ops.ln_bwd(dh, hh, c.xhat, c.rstd, c.gamma, fus)
+    if getattr(c, "linear", None) is not None:
+        r = c.linear.backward(dz, dW_out=dW_out, db_out=db_out)
+        out.update(r)
+        out["dz"] = dz
+        return out
     if getattr(c, "one", False):
         # 1-wide layer: dx, the partial sums of dW and (with a fused act') of the previous block's bias gradient
         # come out of one launch
@@ -363,6 +395,145 @@ class _MLPBlockFn(torch.autograd.Function):
 
 def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):
     return _MLPBlockFn.apply(x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps)
+
+
+# -------------------------------------------------------------------------------------------------
+# PNN: the first MLP layer over [embeddings | inner products | outer products of all field pairs]
+# -------------------------------------------------------------------------------------------------
+OUTER_BLOCK_BYTES = 192 << 20        # size aimed at for one block of outer products (stays in the 256 MB Infinity Cache)
+
+
+def outer_blocks(Fn: int, d: int, B: int):
+    """[(i_lo, i_hi)]: ranges of the first field of a pair whose products [B, n_pairs*d*d] fill about
+    OUTER_BLOCK_BYTES (a range holds at least one field; pairs are numbered first field major)."""
+    budget = max(1, OUTER_BLOCK_BYTES // (B * d * d * 4))
+    blocks, lo = [], 0
+    while lo < Fn - 1:
+        hi, n = lo + 1, Fn - 1 - lo
+        while hi < Fn - 1 and n + (Fn - 1 - hi) <= budget:
+            n += Fn - 1 - hi
+            hi += 1
+        blocks.append((lo, hi))
+        lo = hi
+    return blocks
+
+
+class OuterLinear:
+    """z = [x_other | outer(emb)] W^T + b without the (B, P*d*d) matrix of outer products (model/PNN/PNN.py:80-103
+    feeding PNN.py:19-27,58: 189,696 columns at F = 39, d = 16, 3.1 GB at B = 4096): the reduction dimension is walked a
+    block of pairs at a time -- products of the block written, multiplied into the running sum (rs_gemm_f32_acc),
+    buffer reused -- and the backward recomputes each block to form its columns of dW and its share of demb.  W's rows
+    (K0 + P*d*d floats, not a multiple of four) are first copied into a shadow whose two column groups start 16-byte
+    aligned, so every product runs on the DMA GEMM; dW is built in the same layout and copied back."""
+
+    def __init__(self, emb, x_other, W, b):
+        self.emb = emb.contiguous()                       # [B, F, d]
+        B, Fn, d = self.emb.shape
+        self.B, self.F, self.d = B, Fn, d
+        self.dd = d * d
+        self.K0 = 0 if x_other is None else x_other.shape[1]
+        self.K0p = (self.K0 + 3) // 4 * 4
+        self.KO = Fn * (Fn - 1) // 2 * self.dd
+        if W.shape[1] != self.K0 + self.KO:
+            raise ops.RSError(f"OuterLinear: weight has {W.shape[1]} columns, expected {self.K0} + {self.KO}")
+        self.W, self.b = W, b
+        self.blocks = outer_blocks(Fn, d, B)
+        self.wmax = max((ops.pair_start(hi, Fn) - ops.pair_start(lo, Fn)) * self.dd for lo, hi in self.blocks)
+        self.x_other = x_other
+        self.xo = self.Ws = None
+
+    def _cols(self, lo, hi):
+        off = self.K0p + ops.pair_start(lo, self.F) * self.dd
+        return off, (ops.pair_start(hi, self.F) - ops.pair_start(lo, self.F)) * self.dd
+
+    def forward(self):
+        W, N = self.W.detach(), self.W.shape[0]
+        Ws = torch.empty((N, self.K0p + self.KO), dtype=torch.float32, device=W.device)
+        if self.K0:
+            Ws[:, :self.K0].copy_(W[:, :self.K0])
+            if self.K0p > self.K0:
+                Ws[:, self.K0:self.K0p].zero_()
+        Ws[:, self.K0p:].copy_(W[:, self.K0:])
+        self.Ws = Ws
+        z = torch.empty((self.B, N), dtype=torch.float32, device=W.device)
+        started = False
+        if self.K0:
+            xo = self.x_other
+            if self.K0p > self.K0 or not xo.is_contiguous():
+                xo = _pad_columns(xo, self.K0p - self.K0) if self.K0p > self.K0 else xo.contiguous()
+            self.xo = xo
+            ops.gemm(xo, Ws[:, :self.K0p], out=z)
+            started = True
+        buf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=W.device)
+        for k, (lo, hi) in enumerate(self.blocks):
+            off, w = self._cols(lo, hi)
+            Xb = ops.pnn_outer_fwd_range(self.emb, lo, hi, out=buf[:, :w])
+            last = k == len(self.blocks) - 1
+            ops.gemm(Xb, Ws[:, off:off + w], out=z, accumulate=started, bias=self.b.detach() if last else None)
+            started = True
+        return z
+
+    def backward(self, dz, dW_out=None, db_out=None):
+        Ws, N = self.Ws, self.W.shape[0]
+        dev = dz.device
+        dWs = torch.empty_like(Ws)
+        dxo = None
+        if self.K0:
+            ops.gemm(dz, self.xo, a_mc=True, b_nc=True, out=dWs[:, :self.K0p])
+            dxo = ops.gemm(dz, Ws[:, :self.K0p], b_nc=True)[:, :self.K0]
+        demb = torch.empty_like(self.emb)
+        buf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=dev)
+        gbuf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=dev)
+        for k, (lo, hi) in enumerate(self.blocks):
+            off, w = self._cols(lo, hi)
+            Xb = ops.pnn_outer_fwd_range(self.emb, lo, hi, out=buf[:, :w])
+            ops.gemm(dz, Xb, a_mc=True, b_nc=True, out=dWs[:, off:off + w])
+            G = ops.gemm(dz, Ws[:, off:off + w], b_nc=True, out=gbuf[:, :w])
+            ops.pnn_outer_bwd_range(self.emb, G, lo, hi, demb, accumulate=k > 0)
+        dW = dW_out if dW_out is not None else torch.empty_like(self.W)
+        if self.K0:
+            dW[:, :self.K0].copy_(dWs[:, :self.K0])
+        dW[:, self.K0:].copy_(dWs[:, self.K0p:])
+        db = ops.colsum(dz, out=db_out)
+        self.Ws = self.xo = None
+        return {"dx": None, "dW": dW, "db": db, "demb": demb, "dx_other": dxo}
+
+
+class _PNNOuterBlockFn(torch.autograd.Function):
+    """MLPBlock (Layers.py:39-47) whose input is [x_other | outer products of emb] (PNN.py:58 with pnn_type outer / both),
+    evaluated through OuterLinear."""
+
+    @staticmethod
+    def forward(ctx, emb, x_other, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps):
+        lin = OuterLinear(emb, x_other, W, b)
+        h, c = mlp_block_fwd(None, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps, linear=lin)
+        ctx.c = c
+        ctx.pids = (id(W), id(b))
+        c.h = None
+        ctx.save_for_backward(h)
+        ctx.has_other = x_other is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        cap = TableCapture.active
+        sW = sb = None
+        if cap is not None and cap.grad_sinks:
+            sW, sb = cap.sink(ctx.pids[0]), cap.sink(ctx.pids[1])
+        ctx.c.h, = ctx.saved_tensors
+        r = mlp_block_bwd(dh.contiguous(), ctx.c, dW_out=sW, db_out=sb)
+        ctx.c.h = None
+        return (r["demb"], r["dx_other"] if ctx.has_other else None, None if sW is not None else r["dW"],
+                None if sb is not None else r["db"], r["dgamma"], r["dbeta"], r["dslope"], None, None, None, None, None, None)
+
+
+def pnn_outer_block(block, emb, x_other):
+    """`block` (an MLPBlock) applied to cat([x_other, outer products of emb], 1) without building that matrix."""
+    gamma, beta, rm, rv, eps = block._norm_args()
+    slope = block.activation_func.weight if block._act == ACT_CODES["prelu"] else None
+    h = _PNNOuterBlockFn.apply(emb, x_other, block.fc.weight, block.fc.bias, gamma, beta, slope, block._act,
+                               block.normalization or None, block.training, rm, rv, eps)
+    return block.dropout(h)
 
 
 _dropout_calls = 0

@@ -215,9 +215,14 @@ class PNN(_CTRModel):
     def logits(self, x):
         x = self.features_to_divice(x)
         emb_out = self.embedding_layer(x)
-        pnn_output = {"inner": self.inner_product, "outer": self.outer_product, "both": self.both_product}[self.pnn_type](
-            emb_out)
-        return self.mlp(torch.cat([emb_out.view(emb_out.shape[0], -1), pnn_output], dim=1))
+        flat = emb_out.view(emb_out.shape[0], -1)
+        if self.pnn_type == "inner":
+            return self.mlp(torch.cat([flat, self.inner_product(emb_out)], dim=1))
+        # The outer products are 741 * 256 values per sample at F = 39, d = 16: the first block takes them a block of
+        # pairs at a time (functional.OuterLinear) instead of reading cat([flat, pnn_output]) (PNN.py:58); the columns
+        # of its weight keep the reference's order [embeddings | inner | outer].
+        other = flat if self.pnn_type == "outer" else torch.cat([flat, self.inner_product(emb_out)], dim=1)
+        return self.mlp[1:](Fn.pnn_outer_block(self.mlp[0], emb_out, other))
 
 
 class NFM(_CTRModel):

@@ -26,6 +26,21 @@ def _chk(t: Optional[torch.Tensor], dtype, name: str, shape=None):
     require_cuda(t)
 
 
+def _chk_rows(t: Optional[torch.Tensor], name: str, shape=None):
+    """A float32 matrix whose rows are contiguous but may lie further apart than their length (a block of columns of
+    a wider matrix): what the GEMM's leading-dimension arguments describe.  Returns the row stride in elements."""
+    if t is None:
+        return 0
+    if t.dtype != torch.float32:
+        raise RSError(f"{name}: expected dtype torch.float32, got {t.dtype}")
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        raise RSError(f"{name}: must be a 2-D tensor with contiguous rows")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RSError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    require_cuda(t)
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
 class FieldLayout:
     """Where each field's rows sit in the stacked table: device copies of row_offset/vocab."""
 
@@ -160,31 +175,32 @@ _gemm_plans = {}       # (M, N, K) -> (tile, splitk) of rs_gemm_plan
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
          mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None,
-         defer_reduce=None) -> torch.Tensor:
+         defer_reduce=None, accumulate=False) -> torch.Tensor:
     """C = epi(op(A) op(B)) in fp32 on the matrix cores.
 
     a_mc=False: a is [M, K];  a_mc=True: a is [K, M] (used as its transpose).
     b_nc=False: b is [N, K] (nn.Linear weight);  b_nc=True: b is [K, N].
+    a, b, out and mulsrc may be blocks of columns of wider matrices (contiguous rows, any row stride).
     colsum_part: a ColsumParts collector; the GEMM leaves per-wave-row column sums of C in a scratch buffer and
     registers (buffer, rows, N, destination) with it -- ColsumParts.finish() adds them up in one launch for
     every registered GEMM (the bias gradients of the dZ's the backward chain produces).
     defer_reduce: a SplitKParts collector; a product whose reduction is split leaves its slabs there and `out` is
     only valid after the collector's finish() (one launch for all of them).
+    accumulate: C = act(C + op(A) op(B) + bias) -- one term of a sum over blocks of the reduction dimension.
     """
-    _chk(a, torch.float32, "a")
-    _chk(b, torch.float32, "b")
-    if a.dim() != 2 or b.dim() != 2:
-        raise RSError("gemm: operands must be 2-D")
+    lda = _chk_rows(a, "a")
+    ldb = _chk_rows(b, "b")
     M, K = (a.shape[1], a.shape[0]) if a_mc else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[1], b.shape[0]) if b_nc else (b.shape[0], b.shape[1])
     if K != Kb:
         raise RSError(f"gemm: inner dimensions differ ({K} vs {Kb})")
     _chk(bias, torch.float32, "bias", (N,))
-    _chk(mulsrc, torch.float32, "mulsrc", (M, N))
+    ldm = _chk_rows(mulsrc, "mulsrc", (M, N))
     if out is None:
+        if accumulate:
+            raise RSError("gemm: accumulate needs the running sum in `out`")
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    else:
-        _chk(out, torch.float32, "out", (M, N))
+    ldc = _chk_rows(out, "out", (M, N))
     if M == 0 or N == 0:
         return out
     h = _lib.lib()
@@ -201,11 +217,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
             splitk = plan[1]
     ws = ws or default_workspace(a.device)
     if (defer_reduce is not None and splitk > 1 and splitk * 32 <= K and bias is None and act == 0 and mulsrc is None
-            and colsum_part is None and out.is_contiguous()):
+            and colsum_part is None and out.is_contiguous() and not accumulate):
         # slabs only; `out` is written by defer_reduce.finish()
         wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
         wbuf = defer_reduce.buffer(wbytes // 4)
-        call("rs_gemm_f32_slabs", int(a_mc), int(b_nc), M, N, K, ptr(a), a.shape[1], ptr(b), b.shape[1], int(tile),
+        call("rs_gemm_f32_slabs", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, int(tile),
              int(splitk), ptr(wbuf), wbytes, stream())
         defer_reduce.add(wbuf, out, M * N, splitk)
         return out
@@ -213,16 +229,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     if splitk > 1:
         wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
         wbuf = ws.get("gemm_splitk", wbytes // 4)
+    if accumulate:
+        if mulsrc is not None or colsum_part is not None:
+            raise RSError("gemm: accumulate takes bias and activation only")
+        call("rs_gemm_f32_acc", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, ptr(bias),
+             int(act), int(tile), int(splitk), ptr(wbuf), wbytes, stream())
+        return out
     part = None
     if colsum_part is not None and splitk == 1:
-        aligned = all(t.data_ptr() % 16 == 0 and t.shape[1] % 4 == 0 for t in (a, b))
+        aligned = all(t.data_ptr() % 16 == 0 and ld % 4 == 0 for t, ld in ((a, lda), (b, ldb)))
         if tile in (0, 1) and not aligned:
             tile = 3
         rows = h.rs_gemm_colsum_rows(M, tile)
         part = colsum_part.buffer(rows * N)
         colsum_part.add(part, rows, N, N)
-    call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), a.shape[1], ptr(b), b.shape[1], ptr(out), N,
-         ptr(bias), int(act), ptr(mulsrc), N, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
+    call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+         ptr(bias), int(act), ptr(mulsrc), ldm, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
          stream())
     if colsum_part is not None and part is None:
         colsum(out, out=colsum_part.take_destination(), ws=ws)        # split reduction: separate column-sum launch
@@ -963,6 +985,37 @@ def pnn_outer_bwd(emb: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     _chk(dout, torch.float32, "dout", (B, Fn * (Fn - 1) // 2 * d * d))
     demb = torch.empty_like(emb)
     call("rs_pnn_outer_bwd", ptr(emb), ptr(dout), B, Fn, d, ptr(demb), stream())
+    return demb
+
+
+def pair_start(i: int, F: int) -> int:
+    """Index of pair (i, i+1) in the first-field-major numbering of the F(F-1)/2 pairs (PNN.py:83-85)."""
+    return i * (2 * F - i - 1) // 2
+
+
+def pnn_outer_fwd_range(emb: torch.Tensor, i_lo: int, i_hi: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The outer products of the pairs (i, j), i in [i_lo, i_hi): [B, n_pairs * d * d] (out: a buffer with contiguous
+    rows of at least that length)."""
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    width = (pair_start(i_hi, Fn) - pair_start(i_lo, Fn)) * d * d
+    if out is None:
+        out = torch.empty((B, width), dtype=torch.float32, device=emb.device)
+    ld = _chk_rows(out, "out", (B, width))
+    call("rs_pnn_outer_fwd_range", ptr(emb), B, Fn, d, int(i_lo), int(i_hi), ptr(out), ld, stream())
+    return out
+
+
+def pnn_outer_bwd_range(emb: torch.Tensor, dout: torch.Tensor, i_lo: int, i_hi: int, demb: torch.Tensor,
+                        accumulate: bool) -> torch.Tensor:
+    """demb (+)= the gradient the products of pairs (i, j), i in [i_lo, i_hi), send back to the embeddings."""
+    _chk(emb, torch.float32, "emb")
+    B, Fn, d = emb.shape
+    width = (pair_start(i_hi, Fn) - pair_start(i_lo, Fn)) * d * d
+    ld = _chk_rows(dout, "dout", (B, width))
+    _chk(demb, torch.float32, "demb", (B, Fn, d))
+    call("rs_pnn_outer_bwd_range", ptr(emb), ptr(dout), ld, B, Fn, d, int(i_lo), int(i_hi), int(bool(accumulate)),
+         ptr(demb), stream())
     return demb
 
 

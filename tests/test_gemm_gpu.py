@@ -184,3 +184,35 @@ def test_deferred_splitk_products_reduce_in_one_launch():
     out = ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=1, defer_reduce=coll)
     assert torch.equal(out, ops.gemm(a, b, a_mc=True, b_nc=True, tile=3, splitk=1))
     coll.finish()
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(256, 128, 96, 8), (200, 70, 37, 3), (4096, 1024, 512, 4), (130, 64, 1024, 0)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_column_blocks_and_running_sum(M, N, K, pad, layout):
+    """Operands and result that are blocks of columns of wider matrices (row stride > row length), and
+    rs_gemm_f32_acc: C = act(C + A B + bias) summed over two halves of the reduction dimension."""
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + pad)
+    dev = "cuda:0"
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    want = torch.tanh(A.double() @ Bm.double() + bias.double())
+    bound = A.double().abs() @ Bm.double().abs() + bias.double().abs()
+
+    def block(t):                        # t as columns [pad, pad + width) of a wider matrix
+        wide = torch.full((t.shape[0], t.shape[1] + 2 * pad + 4), float("nan"))
+        wide[:, pad:pad + t.shape[1]] = t
+        return wide.to(dev)[:, pad:pad + t.shape[1]]
+
+    kh = K // 2
+    out = block(torch.zeros(M, N))
+    for k0, k1, last in ((0, kh, False), (kh, K, True)):
+        if layout == "nt":
+            a, b, kw = block(A[:, k0:k1]), block(Bm[k0:k1].t().contiguous()), {}
+        elif layout == "nn":
+            a, b, kw = block(A[:, k0:k1]), block(Bm[k0:k1]), dict(b_nc=True)
+        else:
+            a, b, kw = block(A[:, k0:k1].t().contiguous()), block(Bm[k0:k1]), dict(a_mc=True, b_nc=True)
+        ops.gemm(a, b, out=out, accumulate=k0 > 0, bias=bias.to(dev) if last else None, act=ACT["tanh"] if last else 0, **kw)
+    _check(out, want, bound, rel=4e-6)

@@ -10,5 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$TAG" -o p -- \
     python3 "$ROOT/bench.py" "$@" --cpu-baseline 0 --event-pass 0 > "$OUT/$TAG.json" 2> "$OUT/$TAG.err" || exit 1
 find "$OUT/$TAG" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_stats.csv" \;
-python3 "$ROOT/tools/trace_steps.py" "$(find "$OUT/$TAG" -name "*kernel_trace.csv" | head -1)" 15 field_sort_kernel > "$OUT/${TAG}_steps.txt"
+python3 "$ROOT/tools/trace_steps.py" "$(find "$OUT/$TAG" -name "*kernel_trace.csv" | head -1)" 15 sort > "$OUT/${TAG}_steps.txt"
 rm -rf "$OUT/$TAG"
