@@ -1195,14 +1195,17 @@ class FFMPlan(SparsePlan):
         self.chunk_part_wide = torch.empty((self.F, self.cap, self.width), dtype=torch.float32, device=dev)
         self.n_partials_wide = _lib.lib().rs_ffm_bwd_num_partials(self.F, self.cap)
 
-    def rows(self, idx: torch.Tensor, T: torch.Tensor, dout: torch.Tensor, norm_partials: torch.Tensor):
-        """Sorts idx, then fills the compact row gradients and norm_partials[:n_partials_wide]."""
+    def rows(self, idx: torch.Tensor, T: torch.Tensor, dout: torch.Tensor, norm_partials: torch.Tensor,
+             sorted_already: bool = False):
+        """Sorts idx (unless the plan already holds its sort), then fills the compact row gradients and
+        norm_partials[:n_partials_wide]."""
         Fn, B = idx.shape
         _chk(T, torch.float32, "T", (self.layout.total_rows, self.width))
         _chk(dout, torch.float32, "dout", (B,))
         if norm_partials.numel() < self.n_partials_wide:
             raise RSError("FFM backward: norm_partials too small")
-        self.sort_columnar(idx)
+        if not sorted_already:
+            self.sort_columnar(idx)
         call("rs_ffm_bwd_rows", ptr(self.plan), ptr(idx), ptr(self.layout.row_offset_t), ptr(self.layout.vocab_t), ptr(T),
              ptr(dout), B, self.F, self.cap, self.ffm_d, ptr(self.rowgrad_wide), ptr(self.chunk_part_wide), ptr(norm_partials),
              stream())

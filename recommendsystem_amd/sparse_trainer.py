@@ -157,7 +157,7 @@ class SparseTrainer:
                 return                                # caught up together with the sort of this batch
             if done is None:
                 rs_of = lambda h: self._table_state(h)["rs"] if h is not None else None
-                plan.sort_and_catchup(idx, rs_of(ent["emb"]), rs_of(ent["lr"]))
+                plan.sort_and_catchup(idx, rs_of(ent["main"]), rs_of(ent["lr"]))
                 self._sorted[id(plan)] = idx
                 return
         rs.catch_up(idx, holder.layout, 0)            # the update of this step stamps the rows it steps
@@ -366,7 +366,8 @@ class SparseTrainer:
             grad = lambda kind: group[kind]["out"].grad.contiguous() if kind in group else None
             if "ffm" in group:
                 nw = plan.n_partials_wide
-                plan.rows(idx, group["ffm"]["holder"].stacked, grad("ffm").view(B), P[off:off + nw])     # sorts
+                plan.rows(idx, group["ffm"]["holder"].stacked, grad("ffm").view(B), P[off:off + nw],
+                          sorted_already=self._sorted.get(id(plan)) is idx)
                 if "lr" in group:
                     plan.reduce(P[off + nw:off + n], dlr=grad("lr").view(B))
                 else:
@@ -374,14 +375,14 @@ class SparseTrainer:
             else:
                 if self._sorted.get(id(plan)) is not idx:
                     plan.sort_columnar(idx)
-                if self.exact:
-                    for r in group.values():
-                        self._group_of[id(r["holder"])] = {
-                            "plan": plan, "B": B, "emb": group["emb"]["holder"] if "emb" in group else None,
-                            "lr": group["lr"]["holder"] if "lr" in group else None}
                 ge, gl = grad("emb"), grad("lr")
                 plan.reduce(P[off:off + n], gout=ge.view(B * plan.F, plan.d) if ge is not None else None,
                             dlr=gl.view(B) if gl is not None else None)
+            if self.exact:
+                main = group.get("emb") or group.get("ffm")
+                for r in group.values():
+                    self._group_of[id(r["holder"])] = {"plan": plan, "B": B, "main": main["holder"] if main else None,
+                                                       "lr": group["lr"]["holder"] if "lr" in group else None}
             off += n
         ops.sumsq_partials(self.flat_g, P[off:off + N_DENSE_PARTIALS])
         ops.clip_and_prepare(P, self.max_norm, self.scal, self.step_count, self.hyper)
