@@ -73,6 +73,15 @@ int rs_gemm_plan(int M, int N, int K, int cus, int* splitk_out /* host pointer *
 int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
                 float* workspace, size_t workspace_bytes, float* colsum_part, rs_stream_t stream);
+/* rs_gemm_f32 with the mask of rs_dropout_apply(drop_p, drop_seed, drop_salt, drop_call_host, drop_call_dev) multiplied
+ * into the result (element index m*N + n) after bias and activation and before the mulsrc factor: MLPBlock's
+ * dropout(act(fc(x))) (Layers.py:39-47) in the forward product's epilogue, and in the dX product that feeds such a
+ * block's backward.  drop_p == 0: plain rs_gemm_f32. */
+int rs_gemm_f32_drop(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                     int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act, int tile, int splitk,
+                     float* workspace, size_t workspace_bytes, float* colsum_part, float drop_p,
+                     unsigned long long drop_seed, unsigned drop_salt, unsigned long long drop_call_host,
+                     const long long* drop_call_dev, rs_stream_t stream);
 /* C = act(C + op(A) op(B) + bias): one term of a product whose reduction dimension is walked in several calls, so that
  * the whole left operand never has to exist at once -- the first MLP layer of PNN over the outer products of all field
  * pairs (model/PNN/PNN.py:19-27,58,80-103: 741 * 256 inputs per sample at F = 39, d = 16), evaluated a block of pairs at

@@ -31,6 +31,8 @@ _SIGS = {
     # gemm.hip
     "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
                     I, I, c_f32p, SZ, c_f32p, c_stream],
+    "rs_gemm_f32_drop": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
+                         I, I, c_f32p, SZ, c_f32p, F, C.c_ulonglong, C.c_uint, C.c_ulonglong, c_i64p, c_stream],
     "rs_gemm_f32_acc": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
     "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, SZ, c_stream],
     "rs_colsum_f32_noalloc": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],

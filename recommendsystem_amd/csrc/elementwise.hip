@@ -1,5 +1,6 @@
 // Small fused elementwise / reduction kernels around the GEMMs: loss head, normalisation layers.
 #include "common.h"
+#include "philox.h"
 
 namespace {
 
@@ -507,42 +508,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-// ---- dropout (nn.Dropout in training mode, model/utils/Layers.py:33-37,46) -------------------------------------
-// y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) drawn from a counter-based generator (Philox4x32-10): the bits of
-// element i depend only on (seed, salt, call, i), so the backward pass regenerates the forward's mask from the same
-// four numbers instead of storing it.  One Philox block serves four consecutive elements.
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
+// ---- dropout (nn.Dropout in training mode, model/utils/Layers.py:33-37,46): y[i] = keep(i) ? x[i] / (1 - p) : 0 with
+// the mask of philox.h ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
-                                                            float p, unsigned long long seed, unsigned salt,
-                                                            unsigned long long call_host,
-                                                            const long long* __restrict__ call_dev) {
-    const unsigned long long call = call_host + (call_dev ? (unsigned long long)*call_dev : 0ull);
-    // keep iff u >= p * 2^32 (u uniform on 32 bits): P(keep) = 1 - p
-    const double thr_d = (double)p * 4294967296.0;
-    const unsigned thr = thr_d >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)thr_d;
-    const bool drop_all = p >= 1.f;
-    const float scale = drop_all ? 0.f : 1.f / (1.f - p);
+                                                            DropKey key) {
+    const DropConsts d = drop_consts(key);
     const long long nblk = (n + 3) / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
-        unsigned c[4] = {(unsigned)b, (unsigned)((unsigned long long)b >> 32), (unsigned)call, salt ^ (unsigned)(call >> 32)};
-        philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+        float f[4];
+        drop_factors(d, b, f);
         const long long i0 = b * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const long long i = i0 + e;
-            if (i < n) y[i] = (!drop_all && c[e] >= thr) ? x[i] * scale : 0.f;
+            if (i < n) y[i] = f[e] != 0.f ? x[i] * f[e] : 0.f;
         }
     }
 }
@@ -792,8 +772,8 @@ int rs_dropout_apply(const float* x, float* y, long long n, float p, unsigned lo
     RS_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "rs_dropout_apply: bad arguments");
     RS_CHECK_ARG(p >= 0.f && p <= 1.f, "rs_dropout_apply: dropout probability has to be between 0 and 1, but got %f", (double)p);
     if (n == 0) return RS_OK;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, stream, x, y, n, p, seed, salt,
-                       call_host, call_dev);
+    const DropKey key{p, salt, seed, call_host, call_dev};
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(flat_blocks((n + 3) / 4)), dim3(256), 0, stream, x, y, n, key);
     RS_CHECK_LAUNCH("rs_dropout_apply");
     return RS_OK;
 }

@@ -22,6 +22,7 @@
 // k); the next tile's global loads are issued before the MFMAs of the current tile and written to
 // the other LDS buffer after them (one barrier per k-tile).
 #include "common.h"
+#include "philox.h"
 #include "colsum_finish.h"
 #include "splitk_multi.h"
 #include <stdlib.h>
@@ -51,6 +52,8 @@ struct GemmArgs {
                             // 16 = no LDS fragment reads after the first k-tile
     int defer;              // splitk > 1: leave the slabs in ws, the caller reduces them later (rs_splitk_reduce_multi)
     int accum;              // add what C holds to the product before bias and activation (a sum built up over several calls)
+    int has_drop;           // multiply the activated result by the dropout mask of `drop` (element index m*N + n), before
+    DropKey drop;           // the mulsrc factor: forward of a block with dropout, or the dX product that feeds such a block
 };
 #ifdef RS_GEMM_EXPERIMENT
 #define RS_DBG(g) ((g).dbg)
@@ -71,6 +74,13 @@ __device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int
     if (g.accum) v += g.C[(long long)m * g.ldc + n];
     if (g.bias) v += g.bias[n];
     v = rs_act(g.act, v, 0.f);
+    if (g.has_drop) {
+        const long long flat = (long long)m * g.N + n;
+        float f[4];
+        drop_factors(drop_consts(g.drop), flat >> 2, f);
+        const float fe = f[flat & 3];
+        v = fe != 0.f ? v * fe : 0.f;
+    }
     if (g.mulsrc) v *= act_grad_from_h(g.mul_act, g.mulsrc[(long long)m * g.ldm + n]);
     return v;
 }
@@ -457,6 +467,8 @@ __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM 
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!partial && g.bias && n < g.N) bv = *reinterpret_cast<const float4*>(g.bias + n);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    DropConsts dc{};
+    if (!partial && g.has_drop) dc = drop_consts(g.drop);
 #pragma unroll
     for (int p = 0; p < BM / RPP; ++p) {
         const int row = p * RPP + rr, m = m0 + row;
@@ -469,6 +481,12 @@ __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM 
                 }
                 v.x = rs_act(g.act, v.x + bv.x, 0.f); v.y = rs_act(g.act, v.y + bv.y, 0.f);
                 v.z = rs_act(g.act, v.z + bv.z, 0.f); v.w = rs_act(g.act, v.w + bv.w, 0.f);
+                if (g.has_drop) {                      // N % 4 == 0 here: the float4 is one block of the mask
+                    float f[4];
+                    drop_factors(dc, ((long long)m * g.N + n) >> 2, f);
+                    v.x = f[0] != 0.f ? v.x * f[0] : 0.f; v.y = f[1] != 0.f ? v.y * f[1] : 0.f;
+                    v.z = f[2] != 0.f ? v.z * f[2] : 0.f; v.w = f[3] != 0.f ? v.w * f[3] : 0.f;
+                }
                 if (g.mulsrc) {
                     const float4 h = *reinterpret_cast<const float4*>(g.mulsrc + (long long)m * g.ldm + n);
                     v.x *= act_grad_from_h(g.mul_act, h.x); v.y *= act_grad_from_h(g.mul_act, h.y);
@@ -882,7 +900,7 @@ int rs_gemm_colsum_rows(int M, int tile) { return rs_cdiv(M, (tile == 0 || tile 
 static int gemm_impl(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
                      int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part, int defer,
-                     int accum, hipStream_t stream) {
+                     int accum, const DropKey* drop, hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "rs_gemm_f32: negative size");
     if (M == 0 || N == 0) return RS_OK;
     RS_CHECK_ARG(A && B && C, "rs_gemm_f32: null operand");
@@ -913,6 +931,11 @@ static int gemm_impl(int a_mc, int b_nc, int M, int N, int K, const float* A, in
                          (!mulsrc || (aligned16(mulsrc) && ldm % 4 == 0)) && (splitk == 1 || aligned16(workspace));
     GemmArgs g{A, B, C, bias, mulsrc, M, N, K, lda, ldb, ldc, ldm, act, mul_act, 0, splitk, workspace, colsum_part,
                vec_epi ? 1 : 0, (dbg & 64) ? reinterpret_cast<unsigned*>(workspace) : nullptr, dbg, defer, accum};
+    if (drop && drop->p > 0.f) {
+        RS_CHECK_ARG(drop->p <= 1.f, "rs_gemm_f32_drop: dropout probability has to be between 0 and 1, but got %f", (double)drop->p);
+        g.has_drop = 1;
+        g.drop = *drop;
+    }
     RS_CHECK_ARG(!defer || splitk > 1, "rs_gemm_f32_slabs: the reduction did not split (splitk resolved to %d)", splitk);
     g.kchunk = rs_cdiv(rs_cdiv(K, splitk), BK) * BK;
     if (g.kchunk == 0) g.kchunk = BK;
@@ -930,7 +953,20 @@ int rs_gemm_f32(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda
                 int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part,
                 hipStream_t stream) {
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mulsrc, ldm, mul_act, tile, splitk, workspace,
-                     workspace_bytes, colsum_part, 0, 0, stream);
+                     workspace_bytes, colsum_part, 0, 0, nullptr, stream);
+}
+
+// rs_gemm_f32 with the dropout mask of rs_dropout_apply(p, seed, salt, call_host, call_dev) multiplied into the result
+// (element index m*N + n) after bias and activation and before the mulsrc factor: the forward product of a block whose
+// output goes through dropout, and the dX product whose result is the gradient of such an output.
+int rs_gemm_f32_drop(int a_mc, int b_nc, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int act, const float* mulsrc, int ldm, int mul_act,
+                     int tile, int splitk, float* workspace, size_t workspace_bytes, float* colsum_part, float drop_p,
+                     unsigned long long drop_seed, unsigned drop_salt, unsigned long long drop_call_host,
+                     const long long* drop_call_dev, hipStream_t stream) {
+    const DropKey key{drop_p, drop_salt, drop_seed, drop_call_host, drop_call_dev};
+    return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mulsrc, ldm, mul_act, tile, splitk, workspace,
+                     workspace_bytes, colsum_part, 0, 0, &key, stream);
 }
 
 // C = act(C + op(A) op(B) + bias): one term of a product whose reduction dimension is walked in several calls (the
@@ -939,7 +975,7 @@ int rs_gemm_f32_acc(int a_mc, int b_nc, int M, int N, int K, const float* A, int
                     int ldc, const float* bias, int act, int tile, int splitk, float* workspace, size_t workspace_bytes,
                     hipStream_t stream) {
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, 0, tile, splitk, workspace,
-                     workspace_bytes, nullptr, 0, 1, stream);
+                     workspace_bytes, nullptr, 0, 1, nullptr, stream);
 }
 
 // The split-K product without its reducing launch: the splitk slabs [splitk, M, N] stay in `workspace` (which must
@@ -950,7 +986,7 @@ int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, i
     RS_CHECK_ARG(tile >= 0 && splitk > 1 && workspace, "rs_gemm_f32_slabs: needs an explicit tile, splitk > 1 and a workspace");
     RS_CHECK_ARG(splitk <= rs_cdiv(K, BK), "rs_gemm_f32_slabs: splitk %d exceeds the k-tiles of K=%d", splitk, K);
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, workspace, N, nullptr, RS_ACT_NONE, nullptr, 0, 0, tile, splitk,
-                     workspace, workspace_bytes, nullptr, 1, 0, stream);
+                     workspace, workspace_bytes, nullptr, 1, 0, nullptr, stream);
 }
 
 // C[p][e] = sum_z ws[p][z * total[p] + e], z < splitk[p] in slab order, e < total[p], for p < count (<= 8) products in

@@ -310,9 +310,10 @@ class FusedTrainer:
                 if b._act == ACT_CODES["prelu"]:
                     slope = b.activation_func.weight.data
                 h, c = Fn.mlp_block_fwd(h, b.fc.weight.data, b.fc.bias.data, b._act, b.normalization or None, gamma,
-                                        beta, slope, self.model.training, rm, rv, eps)
+                                        beta, slope, self.model.training, rm, rv, eps,
+                                        dropout=self._drop_key(b) if self._drops(b) else None)
                 cs.append(c)
-                if self._drops(b):
+                if self._drops(b) and not c.drop_fused:
                     h = self._dropout(h, b)              # c.h stays the activation before the mask (act' needs it)
             ctx["mlp"] = cs
             if h is not None:
@@ -375,10 +376,14 @@ class FusedTrainer:
         """Block b's output goes through dropout in this pass (Layers.py:33-37,46)."""
         return b is not None and bool(b.dropout.p) and self.model.training
 
+    def _drop_key(self, b):
+        """(p, seed, salt, call_no, call_dev) of block b's mask at the current step: the device step counter numbers it,
+        so both passes of a step -- and every replay of a captured step -- agree."""
+        return (float(b.dropout.p), torch.initial_seed(), int(b.dropout.salt), 0, self.step_count)
+
     def _dropout(self, x, b):
-        """The mask of block b at the current step, applied to an activation (forward) or to a gradient (backward):
-        the device step counter numbers it, so both passes of a step -- and every replay of a captured step -- agree."""
-        return ops.dropout_apply(x, b.dropout.p, torch.initial_seed(), b.dropout.salt, 0, self.step_count)
+        """The mask of block b at the current step, applied to an activation (forward) or to a gradient (backward)."""
+        return ops.dropout_apply(x, *self._drop_key(b))
 
     def _bump_bn_counters(self):
         for b in self.blocks:
@@ -490,8 +495,12 @@ class FusedTrainer:
             for i in range(top, -1, -1):
                 b, c = self.blocks[i], cs[i]
                 prev = self.blocks[i - 1] if i > 0 else None
+                # a previous block whose mask went into its forward GEMM kept the masked activation: the mask and its
+                # act' (a function of the sign) both ride in this block's dX GEMM
+                prev_masked = self._drops(prev) and cs[i - 1].drop_fused
                 fuse_prev = (prev is not None and not prev.normalization and prev._act in (1, 2, 3)
-                             and not self._drops(prev))
+                             and (not self._drops(prev) or prev_masked))
+                mask_key = self._drop_key(prev) if (fuse_prev and prev_masked) else None
                 if not b.normalization and b._act in _FUSABLE:
                     dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
                     keep.append(dzl)
@@ -507,12 +516,14 @@ class FusedTrainer:
                     if fuse_prev:
                         csp.expect(self.gviews[id(prev.fc.bias)])
                     dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
-                                  mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None)
+                                  mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,
+                                  dropout=mask_key)
                     db_done = fuse_prev
                 else:
                     r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
                                          dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
-                                         mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0)
+                                         mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0,
+                                         dx_dropout=mask_key)
                     if b.normalization:
                         self.gviews[id(b.norm_layer.weight)].copy_(r["dgamma"])
                         self.gviews[id(b.norm_layer.bias)].copy_(r["dbeta"])
@@ -521,7 +532,7 @@ class FusedTrainer:
                     dh = r["dx"]
                     keep.append(r)
                     db_done = False
-                if self._drops(prev):
+                if self._drops(prev) and mask_key is None:
                     dh = self._dropout(dh, prev)         # this block read the masked activation of the previous one
                 dz_ready = fuse_prev
                 keep.append(dh)

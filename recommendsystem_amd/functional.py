@@ -13,6 +13,7 @@ from . import ops
 from .ops import ACT_CODES, FieldLayout, SparsePlan
 
 _FUSABLE = (0, 1, 2, 3)      # none / relu / tanh / leakyrelu can ride in the GEMM epilogue
+_SIGN_ACTS = (0, 1, 3)       # none / relu / leakyrelu: the derivative is a function of the sign of the output
 _ONE_WIDE_MAX_K = 1024       # widest input rs_head_bwd takes
 _PAD_MIN_K = 64              # narrower odd inputs are not worth the two padding copies
 
@@ -202,7 +203,7 @@ def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
 # -------------------------------------------------------------------------------------------------
 class MLPCtx:
     __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps", "k", "one",
-                 "linear")
+                 "linear", "drop_fused")
 
 
 def _pad_columns(t, pad: int):
@@ -214,17 +215,21 @@ def _pad_columns(t, pad: int):
 
 
 def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=None, slope=None, training=True,
-                  running_mean=None, running_var=None, eps=1e-5, allow_pad=False, linear=None):
+                  running_mean=None, running_var=None, eps=1e-5, allow_pad=False, linear=None, dropout=None):
     """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx).
 
     allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width).
     linear: an object whose forward() returns x W^T + b and whose backward(dz) returns dict(dx, dW, db) in place of the
-    plain GEMMs (OuterLinear: an input too wide to exist at once); x2d is then ignored."""
+    plain GEMMs (OuterLinear: an input too wide to exist at once); x2d is then ignored.
+    dropout: the (p, seed, salt, call_no, call_dev) key of the block's dropout.  Where the mask can ride in the GEMM's
+    epilogue (no normalisation, an activation whose derivative only needs the sign of its output) the returned h is
+    already masked and ctx.drop_fused is set; otherwise the caller applies the mask."""
     c = MLPCtx()
     c.x, c.W, c.act, c.norm, c.gamma, c.slope, c.eps = x2d, W, act, norm, gamma, slope, eps
     c.z = c.y = c.xhat = c.var = c.rstd = None
     c.k = W.shape[1]
     c.linear = linear
+    c.drop_fused = False
     if linear is not None:
         c.one = False
         z = linear.forward()
@@ -262,7 +267,9 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
     fus = act if act in _FUSABLE else 0
     if not norm:
         if act in _FUSABLE:
-            c.h = ops.gemm(x2d, W, bias=b, act=act)
+            # relu / leakyrelu / none: act'(h) and act'(mask * h) agree wherever the mask lets a gradient through
+            c.drop_fused = dropout is not None and dropout[0] > 0 and act in _SIGN_ACTS
+            c.h = ops.gemm(x2d, W, bias=b, act=act, dropout=dropout if c.drop_fused else None)
         else:                                   # PReLU: keep z for the slope gradient
             c.z = ops.gemm(x2d, W, bias=b)
             c.h = ops.act_fwd(c.z, act, slope)
@@ -283,7 +290,7 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
 
 
 def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0,
-                  defer_reduce=None, colsum_parts=None, dbp_out=None, db_done=False):
+                  defer_reduce=None, colsum_parts=None, dbp_out=None, db_done=False, dx_dropout=None):
     """Backward of one block.  Returns dict(dx, dW, db, dgamma, dbeta, dslope).
 
     dz_ready: `dh` already is dL/dz (the caller fused act' into the GEMM that produced it).
@@ -291,7 +298,8 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
     dx is the previous block's dL/dz.
     colsum_parts/dbp_out: with a fused act', the launch that produces dx also leaves the partial column sums of dx --
     the previous block's bias gradient -- with the collector (valid in dbp_out after its finish()).
-    db_done: this block's bias gradient is already on its way (the block above left it with the collector)."""
+    db_done: this block's bias gradient is already on its way (the block above left it with the collector).
+    dx_dropout: the previous block's dropout key, to be multiplied into dx in the same epilogue (with mulsrc)."""
     out = {"dgamma": None, "dbeta": None, "dslope": None, "db": None}
     fus = c.act if c.act in _FUSABLE else 0
     if not c.norm:
@@ -353,10 +361,11 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
     if need_dx:
         if mulsrc is not None and colsum_parts is not None and dbp_out is not None:
             colsum_parts.expect(dbp_out)
-            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts)
+            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts,
+                                 dropout=dx_dropout)
             out["dbp_left"] = True
         else:
-            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act)
+            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, dropout=dx_dropout)
     else:
         out["dx"] = None
     out["dz"] = dz
@@ -560,9 +569,10 @@ class _MLPStackFn(torch.autograd.Function):
         h = x2d
         for i, s in enumerate(specs):
             W, b, gamma, beta, slope = params[5 * i:5 * i + 5]
-            h, c = mlp_block_fwd(h, W, b, s.act, s.norm, gamma, beta, slope, s.training, s.rm, s.rv, s.eps, allow_pad=True)
+            h, c = mlp_block_fwd(h, W, b, s.act, s.norm, gamma, beta, slope, s.training, s.rm, s.rv, s.eps, allow_pad=True,
+                                 dropout=s.drop)
             cs.append(c)
-            if s.drop is not None:
+            if s.drop is not None and not c.drop_fused:
                 h = ops.dropout_apply(h, *s.drop)
         ctx.cs, ctx.specs = cs, specs
         ctx.pids = [id(p) if p is not None else None for p in params]
@@ -597,21 +607,27 @@ class _MLPStackFn(torch.autograd.Function):
                 dest[k] = t if t is not None else torch.empty(ctx.shapes[k], dtype=torch.float32, device=dev)
         parts = ops.ColsumParts(ops.default_workspace(dev))
         dh = dout.contiguous()
-        dz_ready = db_done = False
+        dz_ready = db_done = masked = False
         for i in range(n - 1, -1, -1):
             s, c = specs[i], cs[i]
-            if s.drop is not None:
+            if s.drop is not None and not masked:
                 dh = ops.dropout_apply(dh, *s.drop)          # what came in is the gradient of the masked output
             prev = specs[i - 1] if i > 0 else None
             need_dx = i > 0 or ctx.needs_input_grad[0]
-            fuse_prev = (prev is not None and not prev.norm and prev.act in (1, 2, 3) and prev.drop is None
+            # a previous block whose mask went into its forward GEMM keeps the masked activation: its act' (a function of
+            # the sign) and the mask itself both ride in this block's dx GEMM; the row-dot layer's backward has no mask
+            prev_masked = prev is not None and prev.drop is not None and cs[i - 1].drop_fused and not c.one
+            fuse_prev = (prev is not None and not prev.norm and prev.act in (1, 2, 3)
+                         and (prev.drop is None or prev_masked)
                          and dest[5 * (i - 1) + 1] is not None and c.x.shape[1] == c.k)
             gW, gb = dest[5 * i], dest[5 * i + 1]
             r = mlp_block_bwd(dh, c, need_dx=need_dx, dz_ready=dz_ready, dW_out=gW, db_out=gb,
                               mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev.act if fuse_prev else 0,
                               defer_reduce=cap.splitk if (sinks and sunk[5 * i]) else None,
                               colsum_parts=parts if (fuse_prev or c.one) else None,
-                              dbp_out=dest[5 * (i - 1) + 1] if fuse_prev else None, db_done=db_done)
+                              dbp_out=dest[5 * (i - 1) + 1] if fuse_prev else None, db_done=db_done,
+                              dx_dropout=prev.drop if (fuse_prev and prev_masked) else None)
+            masked = fuse_prev and prev_masked
             grads[5 * i + 2], grads[5 * i + 3], grads[5 * i + 4] = r["dgamma"], r["dbeta"], r["dslope"]
             dh = r["dx"]
             # the previous block's bias gradient is on its way if this block's dx launch left its partial sums

@@ -175,7 +175,7 @@ _gemm_plans = {}       # (M, N, K) -> (tile, splitk) of rs_gemm_plan
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None,
          mul_act=0, out=None, tile=-1, splitk=0, ws: Optional[Workspace] = None, colsum_part=None,
-         defer_reduce=None, accumulate=False) -> torch.Tensor:
+         defer_reduce=None, accumulate=False, dropout=None) -> torch.Tensor:
     """C = epi(op(A) op(B)) in fp32 on the matrix cores.
 
     a_mc=False: a is [M, K];  a_mc=True: a is [K, M] (used as its transpose).
@@ -187,6 +187,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     defer_reduce: a SplitKParts collector; a product whose reduction is split leaves its slabs there and `out` is
     only valid after the collector's finish() (one launch for all of them).
     accumulate: C = act(C + op(A) op(B) + bias) -- one term of a sum over blocks of the reduction dimension.
+    dropout: (p, seed, salt, call_no, call_dev) as for dropout_apply -- the mask is multiplied into the result after bias
+    and activation and before the mulsrc factor.
     """
     lda = _chk_rows(a, "a")
     ldb = _chk_rows(b, "b")
@@ -229,6 +231,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
     if splitk > 1:
         wbytes = h.rs_gemm_workspace_bytes(M, N, splitk)
         wbuf = ws.get("gemm_splitk", wbytes // 4)
+    if dropout is not None and dropout[0] > 0 and (accumulate or (defer_reduce is not None and splitk > 1)):
+        raise RSError("gemm: a dropout mask goes with a plain product only")
     if accumulate:
         if mulsrc is not None or colsum_part is not None:
             raise RSError("gemm: accumulate takes bias and activation only")
@@ -243,9 +247,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
         rows = h.rs_gemm_colsum_rows(M, tile)
         part = colsum_part.buffer(rows * N)
         colsum_part.add(part, rows, N, N)
-    call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
-         ptr(bias), int(act), ptr(mulsrc), ldm, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
-         stream())
+    if dropout is not None and dropout[0] > 0:
+        p_, seed, salt, call_no, call_dev = dropout
+        call("rs_gemm_f32_drop", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+             ptr(bias), int(act), ptr(mulsrc), ldm, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
+             float(p_), int(seed) & 0xFFFFFFFFFFFFFFFF, int(salt) & 0xFFFFFFFF, int(call_no), ptr(call_dev), stream())
+    else:
+        call("rs_gemm_f32", int(a_mc), int(b_nc), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+             ptr(bias), int(act), ptr(mulsrc), ldm, int(mul_act), int(tile), int(splitk), ptr(wbuf), wbytes, ptr(part),
+             stream())
     if colsum_part is not None and part is None:
         colsum(out, out=colsum_part.take_destination(), ws=ws)        # split reduction: separate column-sum launch
     return out

@@ -179,3 +179,38 @@ def test_generic_trainer_draws_a_fresh_mask_at_every_graph_replay():
         a = m.logits({c: idxs[0][i] for i, c in enumerate(rec.features)})
         b = m.logits({c: idxs[0][i] for i, c in enumerate(rec.features)})
     assert torch.equal(a, b)                                               # evaluation: no dropout
+
+
+@pytest.mark.parametrize("act", ["relu", "leakyrelu", "tanh"])
+def test_stack_with_dropout_in_the_gemm_epilogues(act):
+    """layers.MLPStack with dropout on its first two blocks: for relu / leakyrelu the mask rides in the forward GEMM's
+    epilogue and, with act', in the next block's dX GEMM (rs_gemm_f32_drop); tanh takes the separate launches.  Either
+    way the result is the oracle's with the same multipliers applied behind the blocks."""
+    from recommendsystem_amd import functional as Fn
+    from recommendsystem_amd import layers, ops
+    torch.manual_seed(21)
+    B = 320
+    blocks = [layers.MLPBlock(36, 64, act, None, dropout_rate=0.5), layers.MLPBlock(64, 32, act, None, dropout_rate=0.25),
+              layers.MLPBlock(32, 8, act, None)]
+    stack = layers.MLPStack(*blocks).cuda().train()
+    x = torch.randn(B, 36)
+    g = torch.randn(B, 8)
+    xg = x.cuda().requires_grad_(True)
+    calls0 = Fn._dropout_calls
+    y = stack(xg)
+    seed = torch.initial_seed()
+    masks = [ops.dropout_apply(torch.ones(B, w, device="cuda"), p, seed, blk.dropout.salt, calls0 + k + 1).cpu()
+             for k, (blk, w, p) in enumerate(((blocks[0], 64, 0.5), (blocks[1], 32, 0.25)))]
+    assert all(0 < int((m == 0).sum()) < m.numel() for m in masks)
+    y.backward(g.cuda())
+    xr = x.clone().requires_grad_(True)
+    ps = [(b.fc.weight.detach().cpu().requires_grad_(True), b.fc.bias.detach().cpu().requires_grad_(True)) for b in blocks]
+    h = O.mlp_block(xr, ps[0][0], ps[0][1], act, None) * masks[0]
+    h = O.mlp_block(h, ps[1][0], ps[1][1], act, None) * masks[1]
+    yr = O.mlp_block(h, ps[2][0], ps[2][1], act, None)
+    yr.backward(g)
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-5, atol=2e-6)
+    for b, (W, bias) in zip(blocks, ps):
+        torch.testing.assert_close(b.fc.weight.grad.cpu(), W.grad, rtol=1e-5, atol=5e-6)
+        torch.testing.assert_close(b.fc.bias.grad.cpu(), bias.grad, rtol=1e-5, atol=5e-6)
