@@ -377,16 +377,22 @@ int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, i
 /* ---- row-sharded tables: device side of the all-to-all exchange (no reference counterpart: the
  * reference is single-device; semantics are those of Embedding_layer.forward / its backward on the
  * union of all ranks' batches).  Row i of a field lives on rank i % N at local index i / N + 1. ---- */
-int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, int cap_b, long long* send_idx,
-                   int* route, int* overflow_flag, rs_stream_t stream);
+/* Buckets: (owner o, field f) holds up to capf[f] distinct keys (device int32 [F]; a field with few rows needs no more
+ * than its rows per owner); boff[f] = capf[0] + .. + capf[f-1], S = boff[F].  Key buffers are int64 [N, S + F] with
+ * bucket (o, f) at o*(S+F) + boff[f] + f (count slot, then the keys); row and gradient buffers are [N, S, d] with row r
+ * of bucket (o, f) at position o*S + boff[f] + r, which is also what route[f][u] holds for the u-th distinct key of
+ * field f (-1: the key did not fit, *overflow_flag is set). */
+int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, const int* capf, const int* boff,
+                   int S, long long* send_idx, int* route, int* overflow_flag, rs_stream_t stream);
 int rs_shard_gather(const long long* recv_idx, const int64_t* local_row_offset, const int64_t* local_vocab, int N,
-                    int F, int cap_b, int d, const float* table, const float* table1, float* rows, float* rows1,
-                    int* err_flag, rs_stream_t stream);
-int rs_shard_expand(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rows,
+                    int F, const int* capf, const int* boff, int S, int cap_max, int d, const float* table,
+                    const float* table1, float* rows, float* rows1, int* err_flag, rs_stream_t stream);
+int rs_shard_expand(const int* plan, const int* route, int F, int cap, int d, const float* rows,
                     const float* rows1, float* emb, float* lr1, rs_stream_t stream);
-int rs_shard_pack(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rowgrad,
+int rs_shard_pack(const int* plan, const int* route, int F, int cap, int d, const float* rowgrad,
                   const float* rowgrad1, float* grads, float* grads1, rs_stream_t stream);
-int rs_shard_counts(const long long* recv_idx, int N, int F, int cap_b, int* sub_cnt, rs_stream_t stream);
+int rs_shard_counts(const long long* recv_idx, int N, int F, const int* capf, const int* boff, int S, int* sub_cnt,
+                    rs_stream_t stream);
 
 #ifdef __cplusplus
 }

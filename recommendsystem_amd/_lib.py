@@ -90,11 +90,12 @@ _SIGS = {
     "rs_axpy_f32": [F, c_f32p, c_f32p, L, c_stream],
     "rs_loss_add_reg": [c_f32p, c_f32p, c_i32p, c_f32p, I, c_stream],
     # shard.hip
-    "rs_shard_route": [c_i32p, I, I, c_i64p, I, I, c_i64p, c_i32p, c_i32p, c_stream],
-    "rs_shard_gather": [c_i64p, c_i64p, c_i64p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream],
-    "rs_shard_expand": [c_i32p, c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
-    "rs_shard_pack": [c_i32p, c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
-    "rs_shard_counts": [c_i64p, I, I, I, c_i32p, c_stream],
+    "rs_shard_route": [c_i32p, I, I, c_i64p, I, c_i32p, c_i32p, I, c_i64p, c_i32p, c_i32p, c_stream],
+    "rs_shard_gather": [c_i64p, c_i64p, c_i64p, I, I, c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p,
+                        c_stream],
+    "rs_shard_expand": [c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_shard_pack": [c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_shard_counts": [c_i64p, I, I, c_i32p, c_i32p, I, c_i32p, c_stream],
     # interact.hip
     "rs_fm_fwd": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_fm_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],

@@ -255,6 +255,7 @@ class BaseModel(nn.Module):
                 outputs = self.forward(inputs)
                 val_labels.append(labels.reshape(-1).cpu())
                 val_preds.append(outputs.data.reshape(-1).cpu())
+            self._check_indices()          # the predictions are on the host already: reading the flag adds no wait
             y = torch.cat(val_labels)
             p = torch.cat(val_preds)
             self.last_logloss = log_loss(y, p, eps=1e-7)

@@ -4,8 +4,8 @@
 // zero dummy, so "index 0 = padding, never trained" holds on every rank).  A rank first sorts and
 // de-duplicates its own batch per field (field_sort_kernel), so only DISTINCT rows travel:
 //
-//   requester  route_kernel        distinct keys of field f -> per-owner buckets send_idx[o][f][1+rank]
-//                                  (slot 0 = count), route[f][u] = o*cap_b + rank
+//   requester  route_kernel        distinct keys of field f -> per-owner buckets of send_idx (slot 0 = count, then the
+//                                  keys), route[f][u] = position of the key's row in the row / gradient buffers
 //   (all-to-all of send_idx)
 //   owner      shard_gather_kernel rows for every received local index -> rows[s][f][j][:], rows1[s][f][j]
 //   (all-to-all of rows, rows1)
@@ -15,8 +15,12 @@
 //   (all-to-all of grads, grads1)
 //   owner      field_sort_kernel over the N received sub-lists of each field + reduce + update (sparse.hip)
 //
-// Buckets have a fixed capacity cap_b so that every collective is rectangular and no count ever visits the
-// host; a bucket overflow sets *overflow_flag (checked by the caller outside the step).
+// Buckets have fixed capacities so that every collective is rectangular and no count ever visits the host: bucket
+// (owner o, field f) holds up to capf[f] keys -- a field with few rows never needs more than its rows per owner, which
+// is what keeps the all-to-alls small -- and a bucket overflow sets *overflow_flag (checked by the caller outside the
+// step).  With boff[f] = capf[0] + .. + capf[f-1] and S = boff[F]:
+//   key buffers   [N, S + F] int64: bucket (o, f) starts at o*(S+F) + boff[f] + f (count slot first)
+//   row buffers   [N, S, d]:        row r of bucket (o, f) is at position o*S + boff[f] + r
 #include "common.h"
 #include "plan.h"
 
@@ -53,10 +57,13 @@ template <int IT>
 __global__ __launch_bounds__(RT_THREADS) void route_kernel(const int* __restrict__ plan_seg_row,
                                                            const int* __restrict__ counts,
                                                            const int64_t* __restrict__ row_offset, int F, int cap,
-                                                           int N, int cap_b, long long* __restrict__ send_idx,
+                                                           int N, const int* __restrict__ capf,
+                                                           const int* __restrict__ boff, int S,
+                                                           long long* __restrict__ send_idx,
                                                            int* __restrict__ route, int* __restrict__ overflow_flag) {
     __shared__ int scratch[32];
     const int f = blockIdx.x, t = threadIdx.x;
+    const int cap_b = capf[f], bo = boff[f];
     const int n_seg = counts[f * 4 + 2];
     const int roff = (int)row_offset[f];
     int key[IT], own[IT];
@@ -75,13 +82,13 @@ __global__ __launch_bounds__(RT_THREADS) void route_kernel(const int* __restrict
         for (int j = 0; j < IT; ++j) c += (own[j] == o) ? 1 : 0;
         int total;
         int r = excl_scan_1024(c, scratch, &total);
-        long long* bucket = send_idx + ((long long)o * F + f) * (cap_b + 1);
+        long long* bucket = send_idx + (long long)o * (S + F) + bo + f;
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if (own[j] == o) {
                 if (r < cap_b) {
                     bucket[1 + r] = (long long)(key[j] / N + 1);
-                    route[(long long)f * cap + t * IT + j] = o * cap_b + r;
+                    route[(long long)f * cap + t * IT + j] = o * S + bo + r;
                 } else {
                     route[(long long)f * cap + t * IT + j] = -1;
                 }
@@ -95,26 +102,29 @@ __global__ __launch_bounds__(RT_THREADS) void route_kernel(const int* __restrict
     }
 }
 
-// Owner side: rows for the received local indices.  grid (ceil(cap_b / groups_per_block), N*F).
+// Owner side: rows for the received local indices.  grid (ceil(max capf / groups_per_block), N*F).
 template <int VEC>
 __global__ __launch_bounds__(256) void shard_gather_kernel(const long long* __restrict__ recv_idx,
                                                            const int64_t* __restrict__ local_row_offset,
-                                                           const int64_t* __restrict__ local_vocab, int F, int cap_b,
-                                                           int d, int C, const float* __restrict__ table,
+                                                           const int64_t* __restrict__ local_vocab, int F,
+                                                           const int* __restrict__ capf, const int* __restrict__ boff,
+                                                           int S, int d, int C, const float* __restrict__ table,
                                                            const float* __restrict__ table1, float* __restrict__ rows,
                                                            float* __restrict__ rows1, int* __restrict__ err_flag) {
     const int sf = blockIdx.y;                 // s*F + f
-    const int f = sf % F;
+    const int src = sf / F, f = sf - src * F;
     const int grp = threadIdx.x / C, cc = threadIdx.x - grp * C;
     const int gpb = 256 / C;
     const int j = blockIdx.x * gpb + grp;
-    const long long* bucket = recv_idx + (long long)sf * (cap_b + 1);
+    const int cap_b = capf[f], bo = boff[f];
+    if (grp >= gpb || j >= cap_b) return;
+    const long long* bucket = recv_idx + (long long)src * (S + F) + bo + f;
     const int cnt = (int)bucket[0];
-    if (grp >= gpb || j >= cnt || j >= cap_b) return;
+    if (j >= cnt) return;
     long long li = bucket[1 + j];
     if (li < 0 || li >= local_vocab[f]) { li = 0; if (err_flag) atomicOr(err_flag, 1); }
     const long long row = local_row_offset[f] + li;
-    const long long o = (long long)sf * cap_b + j;
+    const long long o = (long long)src * S + bo + j;
     if (table) {
         if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(rows + o * d + cc * 4) = *reinterpret_cast<const float4*>(table + row * d + cc * 4);
@@ -130,7 +140,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void shard_expand_kernel(const int* __restrict__ sorted_src,
                                                            const int* __restrict__ entry_seg,
                                                            const int* __restrict__ counts,
-                                                           const int* __restrict__ route, int F, int cap, int cap_b,
+                                                           const int* __restrict__ route, int F, int cap,
                                                            int d, int C, const float* __restrict__ rows,
                                                            const float* __restrict__ rows1, float* __restrict__ emb,
                                                            float* __restrict__ lr1) {
@@ -142,13 +152,7 @@ __global__ __launch_bounds__(256) void shard_expand_kernel(const int* __restrict
     const long long src = sorted_src[(long long)f * cap + i];
     const int u = entry_seg[(long long)f * cap + i];
     long long pos = -1;
-    if (u >= 0) {
-        const int code = route[(long long)f * cap + u];
-        if (code >= 0) {
-            const int o = code / cap_b, r = code - o * cap_b;
-            pos = ((long long)o * F + f) * cap_b + r;
-        }
-    }
+    if (u >= 0) pos = route[(long long)f * cap + u];          // -1: the key did not fit its bucket
     if (emb) {
         if constexpr (VEC == 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void shard_expand_kernel(const int* __restrict
 // Requester side: the gradient of each distinct key into its bucket position.
 template <int VEC>
 __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__ counts, const int* __restrict__ route,
-                                                         int F, int cap, int cap_b, int d, int C,
+                                                         int F, int cap, int d, int C,
                                                          const float* __restrict__ rowgrad,
                                                          const float* __restrict__ rowgrad1, float* __restrict__ grads,
                                                          float* __restrict__ grads1) {
@@ -173,10 +177,8 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
     const int gpb = 256 / C;
     const int u = blockIdx.x * gpb + grp;
     if (grp >= gpb || u >= counts[f * 4 + 2]) return;
-    const int code = route[(long long)f * cap + u];
-    if (code < 0) return;
-    const int o = code / cap_b, r = code - o * cap_b;
-    const long long pos = ((long long)o * F + f) * cap_b + r;
+    const long long pos = route[(long long)f * cap + u];
+    if (pos < 0) return;
     const long long g = (long long)f * cap + u;
     if (grads) {
         if constexpr (VEC == 4) {
@@ -189,10 +191,13 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
 }
 
 // Owner side: sub-list descriptors for the merge sort from the count slots of the received buckets.
-__global__ void shard_counts_kernel(const long long* __restrict__ recv_idx, int NF, int cap_b, int* __restrict__ sub_cnt) {
+__global__ void shard_counts_kernel(const long long* __restrict__ recv_idx, int N, int F, const int* __restrict__ capf,
+                                    const int* __restrict__ boff, int S, int* __restrict__ sub_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < NF) {
-        long long c = recv_idx[(long long)i * (cap_b + 1)];
+    if (i < N * F) {
+        const int src = i / F, f = i - src * F;
+        const long long c = recv_idx[(long long)src * (S + F) + boff[f] + f];
+        const int cap_b = capf[f];
         sub_cnt[i] = (int)(c < 0 ? 0 : (c > cap_b ? cap_b : c));
     }
 }
@@ -209,19 +214,20 @@ int lanes(int d, int* VEC, int* C) {
 extern "C" {
 
 // Requester: bucket the distinct keys of a sorted batch by owning rank (key % N); see the file header.
-// plan: the rs_sparse_bwd_sort plan of the local batch (capacity cap per field).
-// send_idx: int64 [N, F, cap_b+1]; route: int32 [F, cap].
-int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, int cap_b, long long* send_idx,
-                   int* route, int* overflow_flag, hipStream_t stream) {
-    RS_CHECK_ARG(plan && row_offset && send_idx && route, "rs_shard_route: null argument");
-    RS_CHECK_ARG(F > 0 && cap > 0 && N > 0 && cap_b > 0, "rs_shard_route: bad sizes");
+// plan: the rs_sparse_bwd_sort plan of the local batch (capacity cap per field).  capf / boff: device int32 [F].
+// send_idx: int64 [N, S + F]; route: int32 [F, cap].
+int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, const int* capf, const int* boff,
+                   int S, long long* send_idx, int* route, int* overflow_flag, hipStream_t stream) {
+    RS_CHECK_ARG(plan && row_offset && send_idx && route && capf && boff, "rs_shard_route: null argument");
+    RS_CHECK_ARG(F > 0 && cap > 0 && N > 0 && S > 0, "rs_shard_route: bad sizes");
+    RS_CHECK_ARG((long long)N * S < (1ll << 31), "rs_shard_route: %d x %d bucket slots do not fit an int", N, S);
     RS_CHECK_ARG(cap <= RT_THREADS * 16, "rs_shard_route: %d entries per field exceed %d", cap, RT_THREADS * 16);
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     int it = 1;
     while (it * RT_THREADS < cap) it <<= 1;
 #define RS_ROUTE(IT)                                                                                         \
     hipLaunchKernelGGL(route_kernel<IT>, dim3(F), dim3(RT_THREADS), 0, stream, pv.seg_row, pv.counts, row_offset, F, \
-                       cap, N, cap_b, send_idx, route, overflow_flag)
+                       cap, N, capf, boff, S, send_idx, route, overflow_flag)
     if (it <= 4) RS_ROUTE(4);
     else if (it == 8) RS_ROUTE(8);
     else RS_ROUTE(16);
@@ -230,26 +236,27 @@ int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, i
     return RS_OK;
 }
 
-// Owner: look up the rows named by the received buckets.  rows: [N, F, cap_b, d]; rows1: [N, F, cap_b].
+// Owner: look up the rows named by the received buckets.  rows: [N, S, d]; rows1: [N, S]; cap_max = max capf.
 int rs_shard_gather(const long long* recv_idx, const int64_t* local_row_offset, const int64_t* local_vocab, int N,
-                    int F, int cap_b, int d, const float* table, const float* table1, float* rows, float* rows1,
-                    int* err_flag, hipStream_t stream) {
-    RS_CHECK_ARG(recv_idx && local_row_offset && local_vocab, "rs_shard_gather: null argument");
+                    int F, const int* capf, const int* boff, int S, int cap_max, int d, const float* table,
+                    const float* table1, float* rows, float* rows1, int* err_flag, hipStream_t stream) {
+    RS_CHECK_ARG(recv_idx && local_row_offset && local_vocab && capf && boff, "rs_shard_gather: null argument");
+    RS_CHECK_ARG(N > 0 && F > 0 && S > 0 && cap_max > 0, "rs_shard_gather: bad sizes");
     RS_CHECK_ARG((table == nullptr) == (rows == nullptr) && (table1 == nullptr) == (rows1 == nullptr),
                  "rs_shard_gather: table/rows mismatch");
     int VEC, C;
     RS_CHECK_ARG(lanes(d, &VEC, &C) == 0, "rs_shard_gather: unsupported d=%d", d);
-    dim3 grid(rs_cdiv(cap_b, 256 / C), N * F), block(256);
+    dim3 grid(rs_cdiv(cap_max, 256 / C), N * F), block(256);
     if (VEC == 4) hipLaunchKernelGGL(shard_gather_kernel<4>, grid, block, 0, stream, recv_idx, local_row_offset, local_vocab,
-                                     F, cap_b, d, C, table, table1, rows, rows1, err_flag);
+                                     F, capf, boff, S, d, C, table, table1, rows, rows1, err_flag);
     else hipLaunchKernelGGL(shard_gather_kernel<1>, grid, block, 0, stream, recv_idx, local_row_offset, local_vocab, F,
-                            cap_b, d, C, table, table1, rows, rows1, err_flag);
+                            capf, boff, S, d, C, table, table1, rows, rows1, err_flag);
     RS_CHECK_LAUNCH("rs_shard_gather");
     return RS_OK;
 }
 
 // Requester: expand the returned distinct rows to the batch.  emb: [B*F, d] (gradient-row order b*F+f).
-int rs_shard_expand(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rows,
+int rs_shard_expand(const int* plan, const int* route, int F, int cap, int d, const float* rows,
                     const float* rows1, float* emb, float* lr1, hipStream_t stream) {
     RS_CHECK_ARG(plan && route, "rs_shard_expand: null argument");
     RS_CHECK_ARG((rows == nullptr) == (emb == nullptr) && (rows1 == nullptr) == (lr1 == nullptr),
@@ -259,15 +266,15 @@ int rs_shard_expand(const int* plan, const int* route, int F, int cap, int cap_b
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     dim3 grid(rs_cdiv(cap, 256 / C), F), block(256);
     if (VEC == 4) hipLaunchKernelGGL(shard_expand_kernel<4>, grid, block, 0, stream, pv.sorted_src, pv.entry_seg, pv.counts,
-                                     route, F, cap, cap_b, d, C, rows, rows1, emb, lr1);
+                                     route, F, cap, d, C, rows, rows1, emb, lr1);
     else hipLaunchKernelGGL(shard_expand_kernel<1>, grid, block, 0, stream, pv.sorted_src, pv.entry_seg, pv.counts, route,
-                            F, cap, cap_b, d, C, rows, rows1, emb, lr1);
+                            F, cap, d, C, rows, rows1, emb, lr1);
     RS_CHECK_LAUNCH("rs_shard_expand");
     return RS_OK;
 }
 
 // Requester: distinct-key gradients (rowgrad [F,cap,d], rowgrad1 [F,cap]) into bucket order.
-int rs_shard_pack(const int* plan, const int* route, int F, int cap, int cap_b, int d, const float* rowgrad,
+int rs_shard_pack(const int* plan, const int* route, int F, int cap, int d, const float* rowgrad,
                   const float* rowgrad1, float* grads, float* grads1, hipStream_t stream) {
     RS_CHECK_ARG(plan && route, "rs_shard_pack: null argument");
     RS_CHECK_ARG((rowgrad == nullptr) == (grads == nullptr) && (rowgrad1 == nullptr) == (grads1 == nullptr),
@@ -276,18 +283,20 @@ int rs_shard_pack(const int* plan, const int* route, int F, int cap, int cap_b, 
     RS_CHECK_ARG(lanes(d, &VEC, &C) == 0, "rs_shard_pack: unsupported d=%d", d);
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     dim3 grid(rs_cdiv(cap, 256 / C), F), block(256);
-    if (VEC == 4) hipLaunchKernelGGL(shard_pack_kernel<4>, grid, block, 0, stream, pv.counts, route, F, cap, cap_b, d, C,
+    if (VEC == 4) hipLaunchKernelGGL(shard_pack_kernel<4>, grid, block, 0, stream, pv.counts, route, F, cap, d, C,
                                      rowgrad, rowgrad1, grads, grads1);
-    else hipLaunchKernelGGL(shard_pack_kernel<1>, grid, block, 0, stream, pv.counts, route, F, cap, cap_b, d, C, rowgrad,
+    else hipLaunchKernelGGL(shard_pack_kernel<1>, grid, block, 0, stream, pv.counts, route, F, cap, d, C, rowgrad,
                             rowgrad1, grads, grads1);
     RS_CHECK_LAUNCH("rs_shard_pack");
     return RS_OK;
 }
 
-// Owner: sub_cnt[s*F+f] = count slot of received bucket (s, f), clamped to [0, cap_b].
-int rs_shard_counts(const long long* recv_idx, int N, int F, int cap_b, int* sub_cnt, hipStream_t stream) {
-    RS_CHECK_ARG(recv_idx && sub_cnt && N > 0 && F > 0 && cap_b > 0, "rs_shard_counts: bad arguments");
-    hipLaunchKernelGGL(shard_counts_kernel, dim3(rs_cdiv(N * F, 256)), dim3(256), 0, stream, recv_idx, N * F, cap_b, sub_cnt);
+// Owner: sub_cnt[s*F+f] = count slot of received bucket (s, f), clamped to [0, capf[f]].
+int rs_shard_counts(const long long* recv_idx, int N, int F, const int* capf, const int* boff, int S, int* sub_cnt,
+                    hipStream_t stream) {
+    RS_CHECK_ARG(recv_idx && sub_cnt && capf && boff && N > 0 && F > 0 && S > 0, "rs_shard_counts: bad arguments");
+    hipLaunchKernelGGL(shard_counts_kernel, dim3(rs_cdiv(N * F, 256)), dim3(256), 0, stream, recv_idx, N, F, capf, boff, S,
+                       sub_cnt);
     RS_CHECK_LAUNCH("rs_shard_counts");
     return RS_OK;
 }

@@ -54,6 +54,13 @@ class ShardSpec:
         cap = int(-(-B // self.N) * slack) + extra
         return min(cap, B)
 
+    def buckets(self, B: int, slack: float = 1.5, extra: int = 64, device=None) -> "BucketLayout":
+        """Per-field bucket capacities: the statistical bound above, but never more than the rows of the field an owner
+        holds (a 100-row field needs 13 slots per owner at N = 8, not B/N * 1.5 + 64) -- those buckets cannot overflow,
+        and the all-to-alls carry a third of the bytes on the Criteo_x1 vocabularies."""
+        cap = self.bucket_capacity(B, slack, extra)
+        return BucketLayout([max(1, min(cap, -(-v // self.N))) for v in self.vocab], device)
+
     def shard_table(self, full: torch.Tensor) -> torch.Tensor:
         """[sum V_f, d] stacked global table -> this rank's stacked local table [sum local_vocab, d]."""
         out, o = [], 0
@@ -73,6 +80,33 @@ class ShardSpec:
                 full[o + r:o + v:self.N] = sh[lo + 1:lo + 1 + n]
                 o += v
                 lo += n + 1
+
+
+class BucketLayout:
+    """Where bucket (owner o, field f) lies in the buffers of the exchange: capf[f] slots per owner, boff[f] = the slots
+    of the fields before f, S slots per owner in all.  Key buffers are [N, S + F] int64 (count slot, then keys), row and
+    gradient buffers [N, S, d]."""
+
+    def __init__(self, capf: List[int], device=None):
+        self.capf = [int(c) for c in capf]
+        self.boff = [0]
+        for c in self.capf[:-1]:
+            self.boff.append(self.boff[-1] + c)
+        self.S = sum(self.capf)
+        self.cap_max = max(self.capf)
+        self.F = len(self.capf)
+        self.capf_t = torch.tensor(self.capf, dtype=torch.int32, device=device)
+        self.boff_t = torch.tensor(self.boff, dtype=torch.int32, device=device)
+
+    def list_tables(self, N: int, device=None):
+        """(sub_off, pay_base) of the N*F key lists an owner receives, list l = s*F + f: first key of bucket (s, f) in the
+        flattened key buffer, and the position of its first row in the row / gradient buffers."""
+        s = torch.arange(N, dtype=torch.int64).view(N, 1)
+        boff = torch.tensor(self.boff, dtype=torch.int64).view(1, self.F)
+        f = torch.arange(self.F, dtype=torch.int64).view(1, self.F)
+        sub_off = (s * (self.S + self.F) + boff + f + 1).reshape(-1).to(torch.int32)
+        pay_base = (s * self.S + boff).reshape(-1).to(torch.int32)
+        return sub_off.to(device), pay_base.to(device)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -195,18 +229,16 @@ class HipShardKernels:
     """The device side of the exchange on librs_hip.so.  tests/test_dist_cpu.py substitutes a torch-CPU
     stand-in with the same methods to rehearse the protocol under gloo."""
 
-    def __init__(self, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool, cap_b: int, device):
-        self.spec, self.B, self.d, self.cap_b = spec, B, d, cap_b
+    def __init__(self, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool, buckets: BucketLayout, device):
+        self.spec, self.B, self.d, self.bk = spec, B, d, buckets
         self.with_emb, self.with_lr = with_emb, with_lr
         self.F = len(spec.vocab)
         self.layout_req = FieldLayout(spec.vocab, device)            # requester: global indices
         self.layout_own = FieldLayout(spec.local_vocab, device)      # owner: local indices (+1 shift)
         self.plan_req = SparsePlan(self.layout_req, cap=B, d=d, with_lr=with_lr)
-        self.plan_own = SparsePlan(self.layout_own, cap=spec.N * cap_b, d=d, with_lr=with_lr)
+        self.plan_own = SparsePlan(self.layout_own, cap=spec.N * buckets.cap_max, d=d, with_lr=with_lr)
         N, F = spec.N, self.F
-        sf = torch.arange(N * F, dtype=torch.int32, device=device)
-        self.sub_off = sf * (cap_b + 1) + 1
-        self.pay_base = sf * cap_b
+        self.sub_off, self.pay_base = buckets.list_tables(N, device)
         self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
         self.scratch_partials = torch.zeros(self.plan_req.n_partials, dtype=torch.float32, device=device)
 
@@ -214,22 +246,29 @@ class HipShardKernels:
         self.plan_req.sort_columnar(idx)
 
     def route(self, send_idx, route, overflow):
+        bk = self.bk
         call("rs_shard_route", ptr(self.plan_req.plan), self.F, self.B, ptr(self.layout_req.row_offset_t), self.spec.N,
-             self.cap_b, ptr(send_idx), ptr(route), ptr(overflow), stream())
+             ptr(bk.capf_t), ptr(bk.boff_t), bk.S, ptr(send_idx), ptr(route), ptr(overflow), stream())
 
     def gather(self, recv_idx, table, table1, rows, rows1):
+        bk = self.bk
         call("rs_shard_gather", ptr(recv_idx), ptr(self.layout_own.row_offset_t), ptr(self.layout_own.vocab_t),
-             self.spec.N, self.F, self.cap_b, self.d, ptr(table), ptr(table1), ptr(rows), ptr(rows1),
-             ptr(self.layout_own.err_flag), stream())
+             self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S, bk.cap_max, self.d, ptr(table), ptr(table1),
+             ptr(rows), ptr(rows1), ptr(self.layout_own.err_flag), stream())
+
+    def _counts(self, recv_idx):
+        bk = self.bk
+        call("rs_shard_counts", ptr(recv_idx), self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S,
+             ptr(self.sub_cnt), stream())
 
     def catch_up(self, recv_idx, rs, rs1):
         """Owner, exact Adam on touched rows: the rows the received buckets name are brought up to the current step
         before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard)."""
-        call("rs_shard_counts", ptr(recv_idx), self.spec.N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
-        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.cap_b, self.layout_own, rs, rs1)
+        self._counts(recv_idx)
+        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.bk.cap_max, self.layout_own, rs, rs1)
 
     def expand(self, route, rows, rows1, emb, lr1):
-        call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d, ptr(rows),
+        call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(rows),
              ptr(rows1), ptr(emb), ptr(lr1), stream())
 
     def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
@@ -239,17 +278,17 @@ class HipShardKernels:
                              colsum=colsum, splitk=splitk)
 
     def pack(self, route, grads, grads1):
-        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d,
+        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d,
              ptr(self.plan_req.rowgrad) if grads is not None else None,
              ptr(self.plan_req.rowgrad1) if grads1 is not None else None, ptr(grads), ptr(grads1), stream())
 
     def merge(self, recv_idx, grads, grads1, partials):
         """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows."""
         N = self.spec.N
-        call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
+        self._counts(recv_idx)
         # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
         self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                  max_entries=N * self.cap_b)
+                                  max_entries=N * self.bk.cap_max)
         self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
                              g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
 
@@ -270,18 +309,16 @@ class HipShardKernelsWide(HipShardKernels):
     """The same device side for rows of W floats (field-aware FFM rows: W = F*d up to 1024), where a row takes a whole
     workgroup instead of a lane group: wide-row segmented reductions on both the requester and the owner side."""
 
-    def __init__(self, spec: ShardSpec, B: int, W: int, cap_b: int, device):
-        self.spec, self.B, self.d, self.cap_b = spec, B, W, cap_b
+    def __init__(self, spec: ShardSpec, B: int, W: int, buckets: BucketLayout, device):
+        self.spec, self.B, self.d, self.bk = spec, B, W, buckets
         self.with_emb, self.with_lr = True, False
         self.F = len(spec.vocab)
         self.layout_req = FieldLayout(spec.vocab, device)
         self.layout_own = FieldLayout(spec.local_vocab, device)
         self.plan_req = WidePlan(self.layout_req, cap=B, W=W)
-        self.plan_own = WidePlan(self.layout_own, cap=spec.N * cap_b, W=W)
+        self.plan_own = WidePlan(self.layout_own, cap=spec.N * buckets.cap_max, W=W)
         N, F = spec.N, self.F
-        sf = torch.arange(N * F, dtype=torch.int32, device=device)
-        self.sub_off = sf * (cap_b + 1) + 1
-        self.pay_base = sf * cap_b
+        self.sub_off, self.pay_base = buckets.list_tables(N, device)
         self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
         self.scratch_partials = torch.zeros(self.plan_req.n_partials_wide, dtype=torch.float32, device=device)
 
@@ -289,15 +326,15 @@ class HipShardKernelsWide(HipShardKernels):
         self.plan_req.reduce_wide(self.scratch_partials, gout)
 
     def pack(self, route, grads, grads1):
-        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.cap_b, self.d,
+        call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d,
              ptr(self.plan_req.rowgrad_wide), None, ptr(grads), None, stream())
 
     def merge(self, recv_idx, grads, grads1, partials):
         N = self.spec.N
-        call("rs_shard_counts", ptr(recv_idx), N, self.F, self.cap_b, ptr(self.sub_cnt), stream())
+        self._counts(recv_idx)
         # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
         self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                  max_entries=N * self.cap_b)
+                                  max_entries=N * self.bk.cap_max)
         self.plan_own.reduce_wide(partials, grads.view(-1, self.d))
 
     def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, rs=None, rs1=None):
@@ -313,26 +350,27 @@ class HipShardKernelsWide(HipShardKernels):
 # -------------------------------------------------------------------------------------------------
 class ShardedExchange:
     def __init__(self, kernels, comm: Comm, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool,
-                 cap_b: int, device):
+                 buckets: BucketLayout, device):
         self.k, self.comm, self.spec = kernels, comm, spec
         N, F = spec.N, len(spec.vocab)
-        self.N, self.F, self.B, self.d, self.cap_b = N, F, B, d, cap_b
+        self.N, self.F, self.B, self.d, self.bk = N, F, B, d, buckets
         self.with_emb, self.with_lr = with_emb, with_lr
         dev = device
+        S = buckets.S
         z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
-        self.send_idx = z((N, F, cap_b + 1), torch.int64)
-        self.recv_idx = z((N, F, cap_b + 1), torch.int64)
+        self.send_idx = z((N, S + F), torch.int64)
+        self.recv_idx = z((N, S + F), torch.int64)
         self.route = torch.full((F, B), -1, dtype=torch.int32, device=dev)
         self.overflow = z((1,), torch.int32)
-        self.rows_s = z((N, F, cap_b, d)) if with_emb else None
-        self.rows_r = z((N, F, cap_b, d)) if with_emb else None
-        self.rows1_s = z((N, F, cap_b)) if with_lr else None
-        self.rows1_r = z((N, F, cap_b)) if with_lr else None
+        self.rows_s = z((N, S, d)) if with_emb else None
+        self.rows_r = z((N, S, d)) if with_emb else None
+        self.rows1_s = z((N, S)) if with_lr else None
+        self.rows1_r = z((N, S)) if with_lr else None
         # gradient buffers reuse the row buffers' shapes
-        self.g_s = z((N, F, cap_b, d)) if with_emb else None
-        self.g_r = z((N, F, cap_b, d)) if with_emb else None
-        self.g1_s = z((N, F, cap_b)) if with_lr else None
-        self.g1_r = z((N, F, cap_b)) if with_lr else None
+        self.g_s = z((N, S, d)) if with_emb else None
+        self.g_r = z((N, S, d)) if with_emb else None
+        self.g1_s = z((N, S)) if with_lr else None
+        self.g1_r = z((N, S)) if with_lr else None
 
     def forward(self, idx, table, table1, emb_out, lr1_out, rs=None, rs1=None):
         """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values.  rs / rs1: ops.RowAdam of
@@ -433,9 +471,9 @@ class DistributedTrainer(FusedTrainer):
 
     def exchange(self, B: int) -> ShardedExchange:
         if B not in self._ex:
-            cap_b = self.spec.bucket_capacity(B, slack=self.bucket_slack)
-            k = HipShardKernels(self.spec, B, self.d, self.has_emb, self.has_lr, cap_b, self.device)
-            ex = ShardedExchange(k, self.comm, self.spec, B, self.d, self.has_emb, self.has_lr, cap_b, self.device)
+            bk = self.spec.buckets(B, slack=self.bucket_slack, device=self.device)
+            k = HipShardKernels(self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
+            ex = ShardedExchange(k, self.comm, self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
             ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
             ex.sq = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._ex[B] = ex
@@ -785,13 +823,13 @@ class DistributedSparseTrainer(SparseTrainer):
         ex = st["ex"].get(B)
         if ex is None:
             spec = st["spec"]
-            cap_b = spec.bucket_capacity(B, slack=self.bucket_slack)
+            bk = spec.buckets(B, slack=self.bucket_slack, device=self.device)
             emb = kind != "lr"
             if kind == "ffm":
-                k = HipShardKernelsWide(spec, B, holder.dim, cap_b, self.device)
+                k = HipShardKernelsWide(spec, B, holder.dim, bk, self.device)
             else:
-                k = HipShardKernels(spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
-            ex = ShardedExchange(k, self.comm, spec, B, holder.dim if emb else 1, emb, not emb, cap_b, self.device)
+                k = HipShardKernels(spec, B, holder.dim if emb else 1, emb, not emb, bk, self.device)
+            ex = ShardedExchange(k, self.comm, spec, B, holder.dim if emb else 1, emb, not emb, bk, self.device)
             ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
             st["ex"][B] = ex
         return st, ex

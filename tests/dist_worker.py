@@ -75,9 +75,10 @@ def run_cpu(outdir):
     assert torch.equal(back, T)
 
     idx, _ = rank_batch(rank)
-    cap_b = spec.bucket_capacity(B)
-    k = TorchShardKernels(spec, B, D, True, True, cap_b)
-    ex = ShardedExchange(k, comm, spec, B, D, True, True, cap_b, "cpu")
+    bk = spec.buckets(B)                       # per-field capacities: small fields get few slots
+    assert min(bk.capf) < max(bk.capf) or len(set(VOCAB)) == 1
+    k = TorchShardKernels(spec, B, D, True, True, bk)
+    ex = ShardedExchange(k, comm, spec, B, D, True, True, bk, "cpu")
     emb, lr1 = torch.full((B * F, D), 9.0), torch.full((B * F,), 9.0)
     ex.forward(idx, shard, shard1, emb, lr1)
     flat = (idx + offsets(VOCAB)).t().reshape(-1)                  # entry b*F+f
@@ -108,8 +109,10 @@ def run_cpu(outdir):
     torch.testing.assert_close(sq[0], (G ** 2).sum() + (G1 ** 2).sum(), rtol=1e-5, atol=0)
 
     # a bucket that is too small is reported, and the collectives still line up
-    k2 = TorchShardKernels(spec, B, D, True, False, 4)
-    ex2 = ShardedExchange(k2, comm, spec, B, D, True, False, 4, "cpu")
+    from recommendsystem_amd.dist import BucketLayout
+    small = BucketLayout([min(4, c) for c in bk.capf])
+    k2 = TorchShardKernels(spec, B, D, True, False, small)
+    ex2 = ShardedExchange(k2, comm, spec, B, D, True, False, small, "cpu")
     ex2.forward(idx, shard, None, emb, None)
     flag = ex2.overflow.clone()
     comm.all_reduce(flag)

@@ -1,15 +1,16 @@
 """Torch-CPU stand-in for recommendsystem_amd.dist.HipShardKernels (test infrastructure only).
 
-Same methods and the same buffer layouts (buckets [N, F, cap_b+1] with the count in slot 0, route codes
-o*cap_b + r, rows [N, F, cap_b, d]), written as plain loops, so that the host-side exchange protocol
+Same methods and the same buffer layouts (dist.BucketLayout: key buffers [N, S + F] with bucket (o, f) at
+o*(S+F) + boff[f] + f, count slot first; row buffers [N, S, d]; route = position o*S + boff[f] + r), written as plain
+loops, so that the host-side exchange protocol
 (ShardedExchange + Comm + ShardSpec) can be rehearsed with the gloo backend on a machine without a GPU.
 """
 import torch
 
 
 class TorchShardKernels:
-    def __init__(self, spec, B, d, with_emb, with_lr, cap_b):
-        self.spec, self.B, self.d, self.cap_b = spec, B, d, cap_b
+    def __init__(self, spec, B, d, with_emb, with_lr, buckets):
+        self.spec, self.B, self.d, self.bk = spec, B, d, buckets
         self.F = len(spec.vocab)
         self.with_emb, self.with_lr = with_emb, with_lr
         self.local_off = [0]
@@ -29,34 +30,40 @@ class TorchShardKernels:
             self.seg_keys.append(uniq)
             self.entry_seg[f, valid] = inv
 
+    def _key_slot(self, o, f):
+        return self.bk.boff[f] + f            # count slot of bucket (o, f) inside row o of a key buffer
+
     def route(self, send_idx, route, overflow):
-        N, cap_b = self.spec.N, self.cap_b
+        N, bk = self.spec.N, self.bk
         send_idx.zero_()
         route.fill_(-1)
         for f in range(self.F):
             keys = self.seg_keys[f]
+            cap_b = bk.capf[f]
             for o in range(N):
                 sel = (keys % N == o).nonzero().view(-1)
                 tot = sel.numel()
                 if tot > cap_b:
                     overflow.fill_(1)
                 n = min(tot, cap_b)
-                send_idx[o, f, 0] = n
-                send_idx[o, f, 1:1 + n] = keys[sel[:n]] // N + 1
-                route[f, sel[:n]] = (o * cap_b + torch.arange(n)).to(route.dtype)
+                k0 = self._key_slot(o, f)
+                send_idx[o, k0] = n
+                send_idx[o, k0 + 1:k0 + 1 + n] = keys[sel[:n]] // N + 1
+                route[f, sel[:n]] = (o * bk.S + bk.boff[f] + torch.arange(n)).to(route.dtype)
 
     def expand(self, route, rows, rows1, emb, lr1):
-        F, B, cap_b = self.F, self.B, self.cap_b
+        F, B = self.F, self.B
+        rows_f = rows.reshape(-1, rows.shape[-1]) if rows is not None else None
+        rows1_f = rows1.reshape(-1) if rows1 is not None else None
         for f in range(F):
             for b in range(B):
                 u = int(self.entry_seg[f, b])
                 code = int(route[f, u]) if u >= 0 else -1
                 if code >= 0:
-                    o, r = divmod(code, cap_b)
                     if emb is not None:
-                        emb[b * F + f] = rows[o, f, r]
+                        emb[b * F + f] = rows_f[code]
                     if lr1 is not None:
-                        lr1[b * F + f] = rows1[o, f, r]
+                        lr1[b * F + f] = rows1_f[code]
                 else:
                     if emb is not None:
                         emb[b * F + f] = 0
@@ -85,28 +92,29 @@ class TorchShardKernels:
                     self.rowgrad1[f, u] += dlr[b]
 
     def pack(self, route, grads, grads1):
-        cap_b = self.cap_b
+        grads_f = grads.view(-1, grads.shape[-1]) if grads is not None else None
+        grads1_f = grads1.view(-1) if grads1 is not None else None
         for f in range(self.F):
             for u in range(self.seg_keys[f].numel()):
                 code = int(route[f, u])
                 if code < 0:
                     continue
-                o, r = divmod(code, cap_b)
                 if grads is not None:
-                    grads[o, f, r] = self.rowgrad[f, u]
+                    grads_f[code] = self.rowgrad[f, u]
                 if grads1 is not None:
-                    grads1[o, f, r] = self.rowgrad1[f, u]
+                    grads1_f[code] = self.rowgrad1[f, u]
 
     # owner -------------------------------------------------------------------------------------
     def gather(self, recv_idx, table, table1, rows, rows1):
         for s in range(self.spec.N):
             for f in range(self.F):
-                n = int(recv_idx[s, f, 0])
-                li = recv_idx[s, f, 1:1 + n] + self.local_off[f]
+                k0, r0 = self._key_slot(s, f), self.bk.boff[f]
+                n = int(recv_idx[s, k0])
+                li = recv_idx[s, k0 + 1:k0 + 1 + n] + self.local_off[f]
                 if rows is not None:
-                    rows[s, f, :n] = table[li]
+                    rows[s, r0:r0 + n] = table[li]
                 if rows1 is not None:
-                    rows1[s, f, :n] = table1[li]
+                    rows1[s, r0:r0 + n] = table1[li]
 
     def merge(self, recv_idx, grads, grads1, partials):
         """Dense local-table gradients (own_grad, own_grad1) = sum of the N requesters' contributions."""
@@ -115,12 +123,13 @@ class TorchShardKernels:
         self.own_grad1 = torch.zeros(R)
         for s in range(self.spec.N):
             for f in range(self.F):
-                n = int(recv_idx[s, f, 0])
-                li = recv_idx[s, f, 1:1 + n] + self.local_off[f]
+                k0, r0 = self._key_slot(s, f), self.bk.boff[f]
+                n = int(recv_idx[s, k0])
+                li = recv_idx[s, k0 + 1:k0 + 1 + n] + self.local_off[f]
                 if grads is not None:
-                    self.own_grad.index_add_(0, li, grads[s, f, :n])
+                    self.own_grad.index_add_(0, li, grads[s, r0:r0 + n])
                 if grads1 is not None:
-                    self.own_grad1.index_add_(0, li, grads1[s, f, :n])
+                    self.own_grad1.index_add_(0, li, grads1[s, r0:r0 + n])
         partials.zero_()
         partials[0] = (self.own_grad ** 2).sum() + (self.own_grad1 ** 2).sum()
 

@@ -29,6 +29,17 @@ def test_shard_spec_partitions_every_row_once():
                 assert torch.equal(shards[i % N][lo + i // N + 1], full[o + i])
             o += v
         assert specs[0].bucket_capacity(4096) <= 4096
+        # per-field buckets: never more slots than rows of the field an owner can hold, never more than the uniform bound
+        bk = specs[0].buckets(4096)
+        cap = specs[0].bucket_capacity(4096)
+        assert bk.capf == [max(1, min(cap, -(-v // N))) for v in vocab]
+        assert bk.S == sum(bk.capf) and bk.boff == [sum(bk.capf[:f]) for f in range(len(vocab))]
+        sub_off, pay_base = bk.list_tables(N)
+        F = len(vocab)
+        for s_ in range(N):
+            for f in range(F):
+                assert int(sub_off[s_ * F + f]) == s_ * (bk.S + F) + bk.boff[f] + f + 1
+                assert int(pay_base[s_ * F + f]) == s_ * bk.S + bk.boff[f]
 
 
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
