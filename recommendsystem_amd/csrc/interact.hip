@@ -1282,6 +1282,320 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
     for (int i = threadIdx.x; i < NP; i += 256) prow[i] = ((sm[i] + sm[region + i]) + sm[2 * region + i]) + sm[3 * region + i];
 }
 
+// ---- matrix-core form of the two wave kernels for d <= 16 ------------------------------------------------------
+// Same mapping (lane j owns field j and the pair it forms with (j + t) mod F in round t), but the three products
+// with the attention matrix leave the vector ALUs, where its A*d wave-uniform values do not fit the scalar
+// registers: per round the 64 pair slots form F/16 tiles of 16 pairs and
+//   Z^T  [A x 16] = W [A x d] . P^T [d x 16]      pre-activations (P staged through LDS, one row per pair),
+//   dP^T [d x 16] = W^T [d x A] . dZ^T [A x 16]   the Z^T tile a lane holds IS the B operand of this product:
+//                                                 its register v carries attention unit a = 4*(lane/16) + v, and
+//                                                 W^T is kept in the matching order, so nothing moves between the two,
+//   dW   [A x d] += dZ^T . P                      summed over pair slots, as in the kernel above,
+// are v_mfma_f32_16x16x4_f32 tiles.  W lives in 4 + d/4 registers per lane, laid out as MFMA operands; h and the
+// bias sit in the four registers that match the rows of Z^T a lane holds.  dP goes back to lane-per-pair order
+// through the LDS rows that staged P.
+template <int D, int A>
+struct AfmOperands {
+    float wz[(D + 3) / 4];   // A operand of Z^T, k-step s: W[a = lane%16][k = 4s + lane/16]
+    float wd[4];             // A operand of dP^T, step v:   W[a = 4*(lane/16) + v][k = lane%16]
+    float hv[4], bz[4];      // h[a], bA[a] for a = 4*(lane/16) + v
+};
+
+template <int D, int A>
+__device__ __forceinline__ void afm_load_operands(AfmOperands<D, A>& o, const float* __restrict__ W,
+                                                  const float* __restrict__ bA, const float* __restrict__ h, int lane) {
+    const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < (D + 3) / 4; ++s) {
+        const int k = 4 * s + g4;
+        o.wz[s] = (r16 < A && k < D) ? W[r16 * D + k] : 0.f;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int a = 4 * g4 + v;
+        o.wd[v] = (a < A && r16 < D) ? W[a * D + r16] : 0.f;
+        o.hv[v] = a < A ? h[a] : 0.f;
+        o.bz[v] = a < A ? bA[a] : 0.f;
+    }
+}
+
+// Z^T tile of the pair slots 16*tile .. 16*tile + 15: register v of lane l = z[a = 4*(l/16) + v] of pair 16*tile + l%16.
+template <int D, int A>
+__device__ __forceinline__ f32x4 afm_z_tile(const AfmOperands<D, A>& o, const float* ps, int tile, int r16, int g4) {
+    constexpr int PS = D + 1;
+    f32x4 c = {o.bz[0], o.bz[1], o.bz[2], o.bz[3]};
+#pragma unroll
+    for (int s = 0; s < (D + 3) / 4; ++s) {
+        const int k = 4 * s + g4;
+        const float b = k < D ? ps[(16 * tile + r16) * PS + k] : 0.f;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wz[s], b, c, 0, 0, 0);
+    }
+    return c;
+}
+
+// Scores of the lane's pairs as in afm_score_pass; ps [64][D+1] stages p (rows of lanes >= F stay zero).
+template <int D, int A, int NT>
+__device__ __forceinline__ float afm_score_pass_mfma(const AfmOperands<D, A>& o, const float* ej, const float* e, float* sc,
+                                                     float* gr, float* ps, int lane, int F,
+                                                     const float* __restrict__ pw) {
+    constexpr int ES = D + 1, PS = D + 1;
+    const int T = F / 2, r16 = lane & 15, g4 = lane >> 4;
+    float m = -INFINITY;
+    for (int t = 1; t <= T; ++t) {
+        int pr = lane + t;
+        if (pr >= F) pr -= F;
+        float gsum = 0.f;
+        if (lane < F) {
+            float ep[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) ep[k] = e[pr * ES + k];      // all reads first: the stores below may not pass them
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float pk = ej[k] * ep[k];
+                gsum = fmaf(pw[k], pk, gsum);
+                ps[lane * PS + k] = pk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // all NT tiles, no branches (rows of unused pair slots are zero): independent chains to interleave
+        f32x4 c[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) c[tt] = afm_z_tile<D, A>(o, ps, tt, r16, g4);
+        float mine = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            float part = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) part = fmaf(o.hv[v], fmaxf(c[tt][v], 0.f), part);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (g4 == tt) mine = part;
+        }
+        __builtin_amdgcn_wave_barrier();                   // p has been consumed before the next round restages it
+        const float s = afm_active(lane, t, F) ? mine : -INFINITY;
+        sc[(t - 1) * 64 + lane] = s;
+        gr[(t - 1) * 64 + lane] = gsum;
+        m = fmaxf(m, s);
+    }
+    return m;
+}
+
+template <int D, int A, int NT>
+__global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const float* __restrict__ emb, int B, int F,
+                                                           const float* __restrict__ W, const float* __restrict__ bA,
+                                                           const float* __restrict__ h, const float* __restrict__ pw,
+                                                           const float* __restrict__ pb, float* __restrict__ out,
+                                                           int region) {
+    extern __shared__ float sm[];
+    constexpr int ES = D + 1, PS = D + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int T = F / 2;
+    float* e = sm + wv * region;
+    float* sc = e + F * ES;
+    float* gr = sc + T * 64;
+    float* ps = gr + T * 64;
+    for (int i = lane; i < 64 * PS; i += 64) ps[i] = 0.f;
+    AfmOperands<D, A> o;
+    afm_load_operands<D, A>(o, W, bA, h, lane);
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        float ej[D];
+        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float m = afm_score_pass_mfma<D, A, NT>(o, ej, e, sc, gr, ps, lane, F, pw);
+        m = wave_max(m);
+        float sum = 0.f, acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float ex = expf(sc[t * 64 + lane] - m);
+            sum += ex;
+            acc = fmaf(ex, gr[t * 64 + lane], acc);
+        }
+        sum = rs_wave_sum(sum);
+        acc = rs_wave_sum(acc);
+        if (lane == 0) out[b] = acc / sum + pb[0];
+    }
+}
+
+template <int D, int A, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void afm_bwd_mfma_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                           int B, int F, const float* __restrict__ W,
+                                                           const float* __restrict__ bA, const float* __restrict__ h,
+                                                           const float* __restrict__ pw, float* __restrict__ demb,
+                                                           float* __restrict__ partials, int region) {
+    extern __shared__ float sm[];
+    constexpr int ES = D + 1, ZS = A + 1, PS = D + 1;
+    constexpr int NP = A * D + 2 * A + D + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int T = F / 2;
+    float* e = sm + wv * region;
+    float* sc = e + F * ES;
+    float* gr = sc + T * 64;
+    float* zs = gr + T * 64;                     // [64][ZS]  dL/dz per pair slot
+    float* ps = zs + 64 * ZS;                    // [64][PS]  p per pair slot, later dL/dp of the same pair
+    for (int i = lane; i < 64 * (ZS + PS); i += 64) zs[i] = 0.f;
+    AfmOperands<D, A> o;
+    afm_load_operands<D, A>(o, W, bA, h, lane);
+    f32x4 accW = {0.f, 0.f, 0.f, 0.f};           // dW[a = 4*g4 + v][k = r16]
+    float accb[4], acch[4], accpw[D], accpb = 0.f;   // accb / acch: attention unit 4*g4 + v, summed over the lane's pair column
+#pragma unroll
+    for (int v = 0; v < 4; ++v) accb[v] = acch[v] = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) accpw[i] = 0.f;
+
+    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
+        float ej[D];
+        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float go = dout[b];
+        float m = afm_score_pass_mfma<D, A, NT>(o, ej, e, sc, gr, ps, lane, F, pw);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float ex = expf(sc[t * 64 + lane] - m);
+            sc[t * 64 + lane] = ex;
+            sum += ex;
+        }
+        const float inv = 1.f / rs_wave_sum(sum);
+        float gbar = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float a = sc[t * 64 + lane] * inv;
+            const float g = go * gr[t * 64 + lane];
+            sc[t * 64 + lane] = a;
+            gr[t * 64 + lane] = g;
+            gbar = fmaf(a, g, gbar);
+        }
+        gbar = rs_wave_sum(gbar);
+        if (lane == 0) accpb += go;
+
+        float de[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) de[k] = 0.f;
+        for (int t = 1; t <= T; ++t) {
+            int pr = lane + t;
+            if (pr >= F) pr -= F;
+            int src = lane - t;
+            if (src < 0) src += F;
+            const float a = sc[(t - 1) * 64 + lane];               // 0 where the lane has no pair in this round
+            const float ds = a * (gr[(t - 1) * 64 + lane] - gbar);
+            float ep[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) ep[k] = 0.f;
+            __builtin_amdgcn_wave_barrier();                       // last round's staging has been consumed
+            if (lane < F) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) ep[k] = e[pr * ES + k];  // all reads first: the stores below may not pass them
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const float pk = ej[k] * ep[k];
+                    ps[lane * PS + k] = pk;
+                    accpw[k] = fmaf(go * a, pk, accpw[k]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // all NT tiles, no branches (rows of unused pair slots are zero): independent chains to interleave
+            f32x4 c[NT], cd[NT];
+            float dst[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                c[tt] = afm_z_tile<D, A>(o, ps, tt, r16, g4);
+                dst[tt] = __shfl(ds, 16 * tt + r16, 64);
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool on = c[tt][v] > 0.f;
+                    const float dz = on ? dst[tt] * o.hv[v] : 0.f;
+                    accb[v] += dz;
+                    acch[v] = fmaf(dst[tt], on ? c[tt][v] : 0.f, acch[v]);
+                    if (4 * g4 + v < A) zs[(16 * tt + r16) * ZS + 4 * g4 + v] = dz;
+                    q = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wd[v], dz, q, 0, 0, 0);
+                }
+                cd[tt] = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h4 = 0; h4 < 4 * NT; h4 += 4) {               // the four k-steps of a tile's pair slots at a time
+                float av[4], bv[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int pl = 4 * (h4 + s4) + g4;
+                    av[s4] = r16 < A ? zs[pl * ZS + r16] : 0.f;
+                    bv[s4] = r16 < D ? ps[pl * PS + r16] : 0.f;
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) accW = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4], accW, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();                       // p has been consumed: its rows now take dL/dp
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (4 * g4 + v < D) ps[(16 * tt + r16) * PS + 4 * g4 + v] = cd[tt][v];
+            }
+            __builtin_amdgcn_wave_barrier();
+            float send[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) send[k] = 0.f;
+            if (lane < F) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const float dp = fmaf(a * go, pw[k], ps[lane * PS + k]);
+                    de[k] = fmaf(dp, ep[k], de[k]);
+                    send[k] = dp * ej[k];
+                }
+            }
+            const bool take = lane < F && afm_active(src, t, F);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float r = __shfl(send[k], src, 64);
+                if (take) de[k] += r;
+            }
+        }
+        if (lane < F) {
+            float4* dst = reinterpret_cast<float4*>(demb + ((long long)b * F + lane) * D);
+#pragma unroll
+            for (int c = 0; c < D / 4; ++c) dst[c] = make_float4(de[4 * c], de[4 * c + 1], de[4 * c + 2], de[4 * c + 3]);
+        }
+    }
+    // per-wave results -> one row per workgroup (waves added in fixed order)
+    __builtin_amdgcn_wave_barrier();
+    float* red = sm + wv * region;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int a_ = 4 * g4 + v;
+        if (a_ < A && r16 < D) red[a_ * D + r16] = accW[v];
+        float tb = accb[v], th = acch[v];
+#pragma unroll
+        for (int o_ = 1; o_ < 16; o_ <<= 1) {
+            tb += __shfl_xor(tb, o_, 64);
+            th += __shfl_xor(th, o_, 64);
+        }
+        if (a_ < A && r16 == 0) { red[A * D + a_] = tb; red[A * D + A + a_] = th; }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float t = rs_wave_sum(accpw[i]);
+        if (lane == 0) red[A * D + 2 * A + i] = t;
+    }
+    const float tpb = rs_wave_sum(accpb);
+    if (lane == 0) red[A * D + 2 * A + D] = tpb;
+    __syncthreads();
+    float* prow = partials + (long long)blockIdx.x * NP;
+    for (int i = threadIdx.x; i < NP; i += 256) prow[i] = ((sm[i] + sm[region + i]) + sm[2 * region + i]) + sm[3 * region + i];
+}
+
 // ---- FFM with true field-aware tables (model/FFM/FFM.py:43-62) -------------------------------------
 // Stacked table T [R, F*d]: row (row_offset[i] + x_i) holds the F vectors of feature value x_i, one per
 // partner field.  out[b] = sum_{i<j} < T[r_i][j], T[r_j][i] >.  One wave per sample, lanes over pairs: the
@@ -1592,23 +1906,34 @@ int pnn_mfma_grid(int B) { const int g = rs_cdiv(B, 4); return g > 2048 ? 2048 :
         default: break;                                                                            \
     }
 
+// The matrix-core AFM kernels with three tiles of 16 pair slots (F <= 48) or four.
+#define RS_AFM_NT_ALIAS(NAME, KERN, NTV)                                                                               \
+    template <int D, int A>                                                                                            \
+    constexpr auto NAME = KERN<D, A, NTV>;
+RS_AFM_NT_ALIAS(afm_fwd_mfma3, afm_fwd_mfma_kernel, 3)
+RS_AFM_NT_ALIAS(afm_fwd_mfma4, afm_fwd_mfma_kernel, 4)
+RS_AFM_NT_ALIAS(afm_bwd_mfma3, afm_bwd_mfma_kernel, 3)
+RS_AFM_NT_ALIAS(afm_bwd_mfma4, afm_bwd_mfma_kernel, 4)
+#undef RS_AFM_NT_ALIAS
+
 // (embedding_dim, attention_dim) instantiated for the wave-per-sample AFM kernels.
 bool afm_wave_shape(int d, int A) {
     return (d == 4 || d == 8 || d == 16 || d == 32) && (A == 4 || A == 8 || A == 16) && A * d <= 256;
 }
-// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays, the backward's per-pair staging
-// [64][A+1 + d+1]; at least one parameter-gradient row.
+// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays, the per-pair staging [64][d+1] of p
+// (+ [64][A+1] of dL/dz in the backward); at least one parameter-gradient row.
 int afm_region_floats(int F, int d, int A, bool bwd) {
-    const int need = F * (d + 1) + 2 * (F / 2) * 64 + (bwd ? 64 * (A + 1 + d + 1) : 0), np = A * d + 2 * A + d + 1;
+    const int need = F * (d + 1) + 2 * (F / 2) * 64 + 64 * (d + 1) + (bwd ? 64 * (A + 1) : 0), np = A * d + 2 * A + d + 1;
     return need > np ? need : np;
 }
+// d <= 16: the matrix-core kernels (KM); d = 32: the vector-ALU wave kernels (KV).
 #define RS_AFM_CASE(K, DD, AA) case (DD) * 100 + (AA): K(DD, AA); break;
-#define RS_AFM_DISPATCH(K)                                                                         \
+#define RS_AFM_DISPATCH(KM, KV)                                                                    \
     switch (d * 100 + A) {                                                                         \
-        RS_AFM_CASE(K, 4, 4) RS_AFM_CASE(K, 4, 8) RS_AFM_CASE(K, 4, 16)                            \
-        RS_AFM_CASE(K, 8, 4) RS_AFM_CASE(K, 8, 8) RS_AFM_CASE(K, 8, 16)                            \
-        RS_AFM_CASE(K, 16, 4) RS_AFM_CASE(K, 16, 8) RS_AFM_CASE(K, 16, 16)                         \
-        RS_AFM_CASE(K, 32, 4) RS_AFM_CASE(K, 32, 8)                                                \
+        RS_AFM_CASE(KM, 4, 4) RS_AFM_CASE(KM, 4, 8) RS_AFM_CASE(KM, 4, 16)                         \
+        RS_AFM_CASE(KM, 8, 4) RS_AFM_CASE(KM, 8, 8) RS_AFM_CASE(KM, 8, 16)                         \
+        RS_AFM_CASE(KM, 16, 4) RS_AFM_CASE(KM, 16, 8) RS_AFM_CASE(KM, 16, 16)                      \
+        RS_AFM_CASE(KV, 32, 4) RS_AFM_CASE(KV, 32, 8)                                              \
         default: break;                                                                            \
     }
 
@@ -1910,10 +2235,22 @@ int rs_afm_fwd(const float* emb, int B, int F, int d, int A, const float* W, con
     if (F <= 64 && afm_wave_shape(d, A) && (reinterpret_cast<uintptr_t>(emb) & 15) == 0) {
         const int region = afm_region_floats(F, d, A, false);
         const int wgrid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
-#define RS_AFM_FW(DD, AA)                                                                                              \
-    hipLaunchKernelGGL((afm_fwd_wave_kernel<DD, AA>), dim3(wgrid), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, \
-                       B, F, W, bA, h, pw, pb, out, region)
-        RS_AFM_DISPATCH(RS_AFM_FW)
+#define RS_AFM_FW(KERN, DD, AA)                                                                                        \
+    do {                                                                                                               \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(KERN<DD, AA>)), "rs_afm_fwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL((KERN<DD, AA>), dim3(wgrid), dim3(256), (size_t)4 * region * sizeof(float), stream, emb, B, \
+                           F, W, bA, h, pw, pb, out, region);                                                          \
+    } while (0)
+#define RS_AFM_FW_M(DD, AA)                                                                                            \
+    do {                                                                                                               \
+        if (F <= 48) RS_AFM_FW(afm_fwd_mfma3, DD, AA);                                                                 \
+        else RS_AFM_FW(afm_fwd_mfma4, DD, AA);                                                                         \
+    } while (0)
+#define RS_AFM_FW_V(DD, AA) RS_AFM_FW(afm_fwd_wave_kernel, DD, AA)
+        RS_CHECK_ARG((size_t)4 * region * sizeof(float) <= LDS_BIG, "rs_afm_fwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);
+        RS_AFM_DISPATCH(RS_AFM_FW_M, RS_AFM_FW_V)
+#undef RS_AFM_FW_M
+#undef RS_AFM_FW_V
 #undef RS_AFM_FW
         RS_CHECK_LAUNCH("rs_afm_fwd");
         return RS_OK;
@@ -1945,13 +2282,21 @@ int rs_afm_bwd(const float* emb, const float* dout, int B, int F, int d, int A, 
     if (F <= 64 && afm_wave_shape(d, A) && ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(demb)) & 15) == 0) {
         const int region = afm_region_floats(F, d, A, true);
         RS_CHECK_ARG((size_t)4 * region * sizeof(float) <= LDS_BIG, "rs_afm_bwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);
-#define RS_AFM_BW(DD, AA)                                                                                              \
+#define RS_AFM_BW(KERN, DD, AA)                                                                                        \
     do {                                                                                                               \
-        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(afm_bwd_wave_kernel<DD, AA>)), "rs_afm_bwd: cannot raise the LDS limit"); \
-        hipLaunchKernelGGL((afm_bwd_wave_kernel<DD, AA>), dim3(rows), dim3(256), (size_t)4 * region * sizeof(float), stream, \
-                           emb, dout, B, F, W, bA, h, pw, demb, partials, region);                                     \
+        RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(KERN<DD, AA>)), "rs_afm_bwd: cannot raise the LDS limit"); \
+        hipLaunchKernelGGL((KERN<DD, AA>), dim3(rows), dim3(256), (size_t)4 * region * sizeof(float), stream, emb,     \
+                           dout, B, F, W, bA, h, pw, demb, partials, region);                                          \
     } while (0)
-        RS_AFM_DISPATCH(RS_AFM_BW)
+#define RS_AFM_BW_M(DD, AA)                                                                                            \
+    do {                                                                                                               \
+        if (F <= 48) RS_AFM_BW(afm_bwd_mfma3, DD, AA);                                                                 \
+        else RS_AFM_BW(afm_bwd_mfma4, DD, AA);                                                                         \
+    } while (0)
+#define RS_AFM_BW_V(DD, AA) RS_AFM_BW(afm_bwd_wave_kernel, DD, AA)
+        RS_AFM_DISPATCH(RS_AFM_BW_M, RS_AFM_BW_V)
+#undef RS_AFM_BW_M
+#undef RS_AFM_BW_V
 #undef RS_AFM_BW
         RS_CHECK_LAUNCH("rs_afm_bwd");
         return RS_OK;
