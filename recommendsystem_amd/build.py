@@ -21,6 +21,9 @@ LIB = os.path.join(LIBDIR, "librs_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-I", CSRC]
+# Per-file additions.  interact.hip: MFMA results are consumed by vector instructions right away, so the products are
+# written to ordinary vector registers instead of accumulation registers that have to be copied out first.
+EXTRA_FLAGS = {"interact.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(src: str, dst: str, deps) -> bool:
@@ -41,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _newer(s, o, hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

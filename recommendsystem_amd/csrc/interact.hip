@@ -1283,101 +1283,171 @@ __global__ __launch_bounds__(256) void afm_bwd_wave_kernel(const float* __restri
 }
 
 // ---- matrix-core form of the two wave kernels for d <= 16 ------------------------------------------------------
-// Same mapping (lane j owns field j and the pair it forms with (j + t) mod F in round t), but the three products
-// with the attention matrix leave the vector ALUs, where its A*d wave-uniform values do not fit the scalar
-// registers: per round the 64 pair slots form F/16 tiles of 16 pairs and
-//   Z^T  [A x 16] = W [A x d] . P^T [d x 16]      pre-activations (P staged through LDS, one row per pair),
-//   dP^T [d x 16] = W^T [d x A] . dZ^T [A x 16]   the Z^T tile a lane holds IS the B operand of this product:
-//                                                 its register v carries attention unit a = 4*(lane/16) + v, and
-//                                                 W^T is kept in the matching order, so nothing moves between the two,
-//   dW   [A x d] += dZ^T . P                      summed over pair slots, as in the kernel above,
-// are v_mfma_f32_16x16x4_f32 tiles.  W lives in 4 + d/4 registers per lane, laid out as MFMA operands; h and the
-// bias sit in the four registers that match the rows of Z^T a lane holds.  dP goes back to lane-per-pair order
-// through the LDS rows that staged P.
+// Same round-robin schedule (pair slot q = field q with partner (q + t) mod F in round t), but the work is laid
+// out as v_mfma_f32_16x16x4_f32 tiles of 16 pair slots and a lane never holds a whole pair: lane l works on pair
+// slot 16*tile + l%16 and on the four embedding dims 4*(l/16) .. +3.  With Wx = [W ; pw] (the projection vector as
+// one more row, so pw.p and dL/dpw ride along):
+//   Z^T  [rows x 16] = Wx . P^T              pre-activations (+ pw.p in row A); P is formed in registers from the
+//                                            lane's own four dims of field q and of its partner (one ds_read_b128),
+//   dP^T [d x 16]    = Wx^T . dZ^T           the Z^T tile a lane holds IS the B operand of this product (register v
+//                                            carries row 4*(l/16) + v, and Wx^T is kept in the matching order); row A
+//                                            of dZ^T is a*dout, which adds the a*dout*pw term of dL/dp,
+//   dWx  [rows x d] += dZ^T . P              summed over pair slots: the one product whose summation index is the
+//                                            pair, so dZ^T and P pass through LDS once, transposed ([row][slot]),
+// and the owner-side embedding gradient accumulates in registers; the partner-side one is added into an LDS copy of
+// the sample's gradient (every field is the partner of exactly one slot per round: no two lanes of an instruction
+// meet).  The softmax over all pairs is taken online in the first pass (running maximum, rescaled sums), so the
+// scores are not stored: the second pass recomputes them from the same instructions, bit for bit.
 template <int D, int A>
-struct AfmOperands {
-    float wz[(D + 3) / 4];   // A operand of Z^T, k-step s: W[a = lane%16][k = 4s + lane/16]
-    float wd[4];             // A operand of dP^T, step v:   W[a = 4*(lane/16) + v][k = lane%16]
-    float hv[4], bz[4];      // h[a], bA[a] for a = 4*(lane/16) + v
+struct AfmMx {
+    static constexpr int AE = A + 1;                      // attention units + the projection row
+    static constexpr int RT = (AE + 15) / 16;             // 16-row tiles of Wx
+    static constexpr int GRT = A / 16, GA = (A % 16) / 4, GV = A % 4;   // row A: row tile, lane group, register
+    static constexpr int KG = D / 4;                      // lane groups that hold embedding dims
+    float wz[RT][4];   // A operand of Z^T, step s:   Wx[16rt + l%16][4*(l/16) + s]
+    float wd[RT][4];   // A operand of dP^T, step v:  Wx[16rt + 4*(l/16) + v][l%16]
+    float hv[RT][4];   // h[a] for a = 16rt + 4*(l/16) + v (0 on row A and below)
+    float bz[RT][4];   // bA[a], likewise
 };
 
-template <int D, int A>
-__device__ __forceinline__ void afm_load_operands(AfmOperands<D, A>& o, const float* __restrict__ W,
-                                                  const float* __restrict__ bA, const float* __restrict__ h, int lane) {
-    const int r16 = lane & 15, g4 = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < (D + 3) / 4; ++s) {
-        const int k = 4 * s + g4;
-        o.wz[s] = (r16 < A && k < D) ? W[r16 * D + k] : 0.f;
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int a = 4 * g4 + v;
-        o.wd[v] = (a < A && r16 < D) ? W[a * D + r16] : 0.f;
-        o.hv[v] = a < A ? h[a] : 0.f;
-        o.bz[v] = a < A ? bA[a] : 0.f;
-    }
+// max(x, 0) in one instruction (fmaxf first quiets a signalling NaN, which an MFMA result never is).
+__device__ __forceinline__ float afm_relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
-// Z^T tile of the pair slots 16*tile .. 16*tile + 15: register v of lane l = z[a = 4*(l/16) + v] of pair 16*tile + l%16.
 template <int D, int A>
-__device__ __forceinline__ f32x4 afm_z_tile(const AfmOperands<D, A>& o, const float* ps, int tile, int r16, int g4) {
-    constexpr int PS = D + 1;
-    f32x4 c = {o.bz[0], o.bz[1], o.bz[2], o.bz[3]};
-#pragma unroll
-    for (int s = 0; s < (D + 3) / 4; ++s) {
-        const int k = 4 * s + g4;
-        const float b = k < D ? ps[(16 * tile + r16) * PS + k] : 0.f;
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wz[s], b, c, 0, 0, 0);
-    }
-    return c;
+__device__ __forceinline__ float afm_wx(const float* __restrict__ W, const float* __restrict__ pw, int a, int k) {
+    if (k >= D) return 0.f;
+    return a < A ? W[a * D + k] : (a == A ? pw[k] : 0.f);
 }
 
-// Scores of the lane's pairs as in afm_score_pass; ps [64][D+1] stages p (rows of lanes >= F stay zero).
-template <int D, int A, int NT>
-__device__ __forceinline__ float afm_score_pass_mfma(const AfmOperands<D, A>& o, const float* ej, const float* e, float* sc,
-                                                     float* gr, float* ps, int lane, int F,
-                                                     const float* __restrict__ pw) {
-    constexpr int ES = D + 1, PS = D + 1;
-    const int T = F / 2, r16 = lane & 15, g4 = lane >> 4;
-    float m = -INFINITY;
-    for (int t = 1; t <= T; ++t) {
-        int pr = lane + t;
-        if (pr >= F) pr -= F;
-        float gsum = 0.f;
-        if (lane < F) {
-            float ep[D];
+template <int D, int A>
+__device__ __forceinline__ void afm_mx_load(AfmMx<D, A>& o, const float* __restrict__ W, const float* __restrict__ bA,
+                                            const float* __restrict__ h, const float* __restrict__ pw, int r16, int g4) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) ep[k] = e[pr * ES + k];      // all reads first: the stores below may not pass them
+    for (int rt = 0; rt < AfmMx<D, A>::RT; ++rt) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const float pk = ej[k] * ep[k];
-                gsum = fmaf(pw[k], pk, gsum);
-                ps[lane * PS + k] = pk;
-            }
+        for (int s = 0; s < 4; ++s) {
+            o.wz[rt][s] = afm_wx<D, A>(W, pw, 16 * rt + r16, 4 * g4 + s);
+            const int a = 16 * rt + 4 * g4 + s;
+            o.wd[rt][s] = afm_wx<D, A>(W, pw, a, r16);
+            o.hv[rt][s] = a < A ? h[a] : 0.f;
+            o.bz[rt][s] = a < A ? bA[a] : 0.f;
         }
-        __builtin_amdgcn_wave_barrier();
-        // all NT tiles, no branches (rows of unused pair slots are zero): independent chains to interleave
-        f32x4 c[NT];
+    }
+}
+
+// One round over all NT tiles, stage by stage so that the tiles' dependency chains interleave: partner dims ->
+// part, p = own * part, Z^T tiles -> c, scores s (every lane) and pw.p (-> g, meaningful in the lanes of group GA).
+// j4[tile] = 4 * partner field of the tile's slot, advanced here by one field per round (wrapping at F; slots beyond
+// F stay on the spare slot F, whose dims are zero).  valid[tile]: the lane's pair slot holds a pair in this round.
+template <int D, int A, int NT>
+__device__ __forceinline__ void afm_mx_round(const AfmMx<D, A>& o, const float* e4, int GS, int F, int t, int r16, int g4,
+                                             const float (&own)[NT][4], float (&part)[NT][4], float (&p)[NT][4],
+                                             f32x4 (&c)[NT][AfmMx<D, A>::RT], float (&s)[NT], float (&g)[NT],
+                                             int (&j4)[NT], bool (&valid)[NT]) {
+    using M = AfmMx<D, A>;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) c[tt] = afm_z_tile<D, A>(o, ps, tt, r16, g4);
-        float mine = 0.f;
+    for (int tt = 0; tt < NT; ++tt) {
+        const int f = 16 * tt + r16;
+        valid[tt] = f < F && (2 * t != F || 2 * f < F);
+        j4[tt] += f < F ? 4 : 0;
+        if (j4[tt] >= 4 * F && f < F) j4[tt] -= 4 * F;
+        const float4 pv = *reinterpret_cast<const float4*>(e4 + g4 * GS + j4[tt]);
+        part[tt][0] = pv.x; part[tt][1] = pv.y; part[tt][2] = pv.z; part[tt][3] = pv.w;
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[tt][k] = own[tt][k] * part[tt][k];
+#pragma unroll
+    for (int rt = 0; rt < M::RT; ++rt) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) c[tt][rt] = f32x4{o.bz[rt][0], o.bz[rt][1], o.bz[rt][2], o.bz[rt][3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                c[tt][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wz[rt][k], p[tt][k], c[tt][rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        float partial = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < M::RT; ++rt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) partial = fmaf(o.hv[rt][v], afm_relu(c[tt][rt][v]), partial);
+        s[tt] = partial;
+        g[tt] = c[tt][M::GRT][M::GV];
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) s[tt] += __shfl_xor(s[tt], 16, 64);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) s[tt] += __shfl_xor(s[tt], 32, 64);
+}
+
+// 4 * partner field before the first round: the slot's own field (the spare slot F for slots beyond F).
+template <int NT>
+__device__ __forceinline__ void afm_mx_start(int (&j4)[NT], int F, int r16) {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) j4[tt] = 16 * tt + r16 < F ? 4 * (16 * tt + r16) : 4 * F;
+}
+
+// First pass over a sample: online softmax statistics of the lane's pair column (lanes of group GA), then the
+// wave-wide maximum, sum of exponentials and sum of exponentials x pw.p.
+template <int D, int A, int NT>
+__device__ __forceinline__ void afm_mx_pass1(const AfmMx<D, A>& o, const float* e4, int GS, int F, int r16, int g4,
+                                             const float (&own)[NT][4], float& mw, float& sumw, float& accw) {
+    using M = AfmMx<D, A>;
+    const int T = F / 2;
+    float m = -INFINITY, sum = 0.f, acc = 0.f;
+    int j4[NT];
+    afm_mx_start<NT>(j4, F, r16);
+    for (int t = 1; t <= T; ++t) {
+        float part[NT][4], p[NT][4], s[NT], g[NT];
+        f32x4 c[NT][M::RT];
+        bool valid[NT];
+        afm_mx_round<D, A, NT>(o, e4, GS, F, t, r16, g4, own, part, p, c, s, g, j4, valid);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            float part = 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) part = fmaf(o.hv[v], fmaxf(c[tt][v], 0.f), part);
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            if (g4 == tt) mine = part;
+            // running maximum: exactly one of the two rescaling factors differs from 1, so one exponential serves
+            const float dlt = s[tt] - m;                   // +inf while m is still -inf
+            const float e1 = __expf(-fabsf(dlt));
+            const bool up = valid[tt] && dlt > 0.f;
+            const float keep = up ? e1 : 1.f;
+            const float ex = valid[tt] ? (up ? 1.f : e1) : 0.f;
+            sum = fmaf(sum, keep, ex);
+            acc = fmaf(acc, keep, ex * g[tt]);
+            m = up ? s[tt] : m;
         }
-        __builtin_amdgcn_wave_barrier();                   // p has been consumed before the next round restages it
-        const float s = afm_active(lane, t, F) ? mine : -INFINITY;
-        sc[(t - 1) * 64 + lane] = s;
-        gr[(t - 1) * 64 + lane] = gsum;
-        m = fmaxf(m, s);
     }
-    return m;
+    const bool mine = g4 == M::GA && m != -INFINITY;
+    mw = wave_max(mine ? m : -INFINITY);
+    const float w = mine ? __expf(m - mw) : 0.f;
+    sumw = rs_wave_sum(sum * w);
+    accw = rs_wave_sum(acc * w);
+}
+
+// Sample b in tile layout: own[tile] = the lane's four dims of field 16*tile + l%16 (zero beyond F and beyond d); the
+// same values go to the LDS copy e4 [4 dim groups][F + 1][4] that partner reads come from (slot F: zeros, the partner
+// of the pair slots beyond F), and the partner-side gradient de4 of the same shape is cleared (its slot F takes the
+// stores of lanes without a pair).
+template <int D, int A, int NT>
+__device__ __forceinline__ void afm_mx_sample(const float* __restrict__ emb, long long b, int F, int GS, int r16, int g4,
+                                              float* e4, float* de4, float (&own)[NT][4]) {
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int f = 16 * tt + r16;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < F && 4 * g4 < D) v = *reinterpret_cast<const float4*>(emb + (b * F + f) * D + 4 * g4);
+        own[tt][0] = v.x; own[tt][1] = v.y; own[tt][2] = v.z; own[tt][3] = v.w;
+        if (f <= F) {
+            *reinterpret_cast<float4*>(e4 + g4 * GS + 4 * f) = v;
+            if (de4) *reinterpret_cast<float4*>(de4 + g4 * GS + 4 * f) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 }
 
 template <int D, int A, int NT>
@@ -1386,208 +1456,176 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const float* __restri
                                                            const float* __restrict__ h, const float* __restrict__ pw,
                                                            const float* __restrict__ pb, float* __restrict__ out,
                                                            int region) {
-    extern __shared__ float sm[];
-    constexpr int ES = D + 1, PS = D + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int T = F / 2;
-    float* e = sm + wv * region;
-    float* sc = e + F * ES;
-    float* gr = sc + T * 64;
-    float* ps = gr + T * 64;
-    for (int i = lane; i < 64 * PS; i += 64) ps[i] = 0.f;
-    AfmOperands<D, A> o;
-    afm_load_operands<D, A>(o, W, bA, h, lane);
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int GS = 4 * (F + 1);
+    float* e4 = sm + wv * region;
+    AfmMx<D, A> o;
+    afm_mx_load<D, A>(o, W, bA, h, pw, r16, g4);
     for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
-        float ej[D];
-        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
+        float own[NT][4];
+        __builtin_amdgcn_wave_barrier();                   // the previous sample's partner reads are done
+        afm_mx_sample<D, A, NT>(emb, b, F, GS, r16, g4, e4, nullptr, own);
         __builtin_amdgcn_wave_barrier();
-        if (lane < F) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
-        }
-        __builtin_amdgcn_wave_barrier();
-        float m = afm_score_pass_mfma<D, A, NT>(o, ej, e, sc, gr, ps, lane, F, pw);
-        m = wave_max(m);
-        float sum = 0.f, acc = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float ex = expf(sc[t * 64 + lane] - m);
-            sum += ex;
-            acc = fmaf(ex, gr[t * 64 + lane], acc);
-        }
-        sum = rs_wave_sum(sum);
-        acc = rs_wave_sum(acc);
-        if (lane == 0) out[b] = acc / sum + pb[0];
+        float mw, sumw, accw;
+        afm_mx_pass1<D, A, NT>(o, e4, GS, F, r16, g4, own, mw, sumw, accw);
+        if (lane == 0) out[b] = accw / sumw + pb[0];
     }
 }
 
 template <int D, int A, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void afm_bwd_mfma_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                           int B, int F, const float* __restrict__ W,
-                                                           const float* __restrict__ bA, const float* __restrict__ h,
-                                                           const float* __restrict__ pw, float* __restrict__ demb,
-                                                           float* __restrict__ partials, int region) {
-    extern __shared__ float sm[];
-    constexpr int ES = D + 1, ZS = A + 1, PS = D + 1;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void afm_bwd_mfma_kernel(
+    const float* __restrict__ emb, const float* __restrict__ dout, int B, int F, const float* __restrict__ W,
+    const float* __restrict__ bA, const float* __restrict__ h, const float* __restrict__ pw, float* __restrict__ demb,
+    float* __restrict__ partials, int region) {
+    using M = AfmMx<D, A>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int NP = A * D + 2 * A + D + 1;
+    constexpr int RS = 16 * NT + 4;                       // row stride of the [row][slot] staging (52 / 68: no bank repeats over 16 rows)
+    constexpr int NS = 4 * NT;                            // k-steps of the dWx product; lane group g holds slots NS*g .. NS*g + NS-1
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r16 = lane & 15, g4 = lane >> 4;
-    const int T = F / 2;
-    float* e = sm + wv * region;
-    float* sc = e + F * ES;
-    float* gr = sc + T * 64;
-    float* zs = gr + T * 64;                     // [64][ZS]  dL/dz per pair slot
-    float* ps = zs + 64 * ZS;                    // [64][PS]  p per pair slot, later dL/dp of the same pair
-    for (int i = lane; i < 64 * (ZS + PS); i += 64) zs[i] = 0.f;
-    AfmOperands<D, A> o;
-    afm_load_operands<D, A>(o, W, bA, h, lane);
-    f32x4 accW = {0.f, 0.f, 0.f, 0.f};           // dW[a = 4*g4 + v][k = r16]
-    float accb[4], acch[4], accpw[D], accpb = 0.f;   // accb / acch: attention unit 4*g4 + v, summed over the lane's pair column
+    const int T = F / 2, GS = 4 * (F + 1);
+    float* e4 = sm + wv * region;                         // [4][F+1][4]   the sample
+    float* de4 = e4 + 4 * GS;                             // [4][F+1][4]   partner-side gradient
+    float* zsT = de4 + 4 * GS;                            // [16*RT][RS]   dZ^T rows by pair slot
+    float* psT = zsT + 16 * M::RT * RS;                   // [16][RS]      P^T rows by pair slot
+    AfmMx<D, A> o;
+    afm_mx_load<D, A>(o, W, bA, h, pw, r16, g4);
+    f32x4 accW[M::RT];                                    // dWx[16rt + 4*g4 + v][r16]
+    float accb[M::RT][4], acch[M::RT][4], accpb = 0.f;    // row 16rt + 4*g4 + v, summed over the lane's pair column
 #pragma unroll
-    for (int v = 0; v < 4; ++v) accb[v] = acch[v] = 0.f;
+    for (int rt = 0; rt < M::RT; ++rt) {
+        accW[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < D; ++i) accpw[i] = 0.f;
+        for (int v = 0; v < 4; ++v) accb[rt][v] = acch[rt][v] = 0.f;
+    }
 
     for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
-        float ej[D];
-        afm_load_row<D>(emb + ((long long)b * F + lane) * D, lane < F, ej);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < F) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) e[lane * ES + k] = ej[k];
-        }
+        float own[NT][4];
+        __builtin_amdgcn_wave_barrier();                   // the previous sample's LDS reads are done
+        afm_mx_sample<D, A, NT>(emb, b, F, GS, r16, g4, e4, de4, own);
         __builtin_amdgcn_wave_barrier();
         const float go = dout[b];
-        float m = afm_score_pass_mfma<D, A, NT>(o, ej, e, sc, gr, ps, lane, F, pw);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float ex = expf(sc[t * 64 + lane] - m);
-            sc[t * 64 + lane] = ex;
-            sum += ex;
-        }
-        const float inv = 1.f / rs_wave_sum(sum);
-        float gbar = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float a = sc[t * 64 + lane] * inv;
-            const float g = go * gr[t * 64 + lane];
-            sc[t * 64 + lane] = a;
-            gr[t * 64 + lane] = g;
-            gbar = fmaf(a, g, gbar);
-        }
-        gbar = rs_wave_sum(gbar);
+        float mw, sumw, accw;
+        afm_mx_pass1<D, A, NT>(o, e4, GS, F, r16, g4, own, mw, sumw, accw);
+        const float inv = 1.f / sumw;
+        const float gbar = go * accw * inv;
         if (lane == 0) accpb += go;
 
-        float de[D];
+        float de[NT][4];
+        int j4[NT];
+        afm_mx_start<NT>(j4, F, r16);
 #pragma unroll
-        for (int k = 0; k < D; ++k) de[k] = 0.f;
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) de[tt][k] = 0.f;
+        // every store of the round below is unconditional (rows and slots without data receive zeros, lanes without
+        // a pair aim at the spare slot F), so the round is one basic block and its tiles interleave
         for (int t = 1; t <= T; ++t) {
-            int pr = lane + t;
-            if (pr >= F) pr -= F;
-            int src = lane - t;
-            if (src < 0) src += F;
-            const float a = sc[(t - 1) * 64 + lane];               // 0 where the lane has no pair in this round
-            const float ds = a * (gr[(t - 1) * 64 + lane] - gbar);
-            float ep[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) ep[k] = 0.f;
-            __builtin_amdgcn_wave_barrier();                       // last round's staging has been consumed
-            if (lane < F) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) ep[k] = e[pr * ES + k];  // all reads first: the stores below may not pass them
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const float pk = ej[k] * ep[k];
-                    ps[lane * PS + k] = pk;
-                    accpw[k] = fmaf(go * a, pk, accpw[k]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // all NT tiles, no branches (rows of unused pair slots are zero): independent chains to interleave
-            f32x4 c[NT], cd[NT];
-            float dst[NT];
+            float part[NT][4], p[NT][4], s[NT], g[NT], ago[NT], ds[NT];
+            f32x4 c[NT][M::RT], q[NT];
+            bool valid[NT];
+            __builtin_amdgcn_wave_barrier();               // last round's staging has been consumed
+            afm_mx_round<D, A, NT>(o, e4, GS, F, t, r16, g4, own, part, p, c, s, g, j4, valid);
+            // attention weight and dL/ds of the pair, in the lanes that hold pw.p; dL/ds then goes to every lane
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                c[tt] = afm_z_tile<D, A>(o, ps, tt, r16, g4);
-                dst[tt] = __shfl(ds, 16 * tt + r16, 64);
+                const float a = valid[tt] ? __expf(s[tt] - mw) * inv : 0.f;
+                ago[tt] = a * go;
+                ds[tt] = a * (go * g[tt] - gbar);
             }
 #pragma unroll
+            for (int tt = 0; tt < NT; ++tt) ds[tt] = __shfl(ds[tt], 16 * M::GA + r16, 64);
+#pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                q[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) psT[(4 * g4 + k) * RS + 16 * tt + r16] = p[tt][k];
+            }
+#pragma unroll
+            for (int rt = 0; rt < M::RT; ++rt) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const bool on = c[tt][v] > 0.f;
-                    const float dz = on ? dst[tt] * o.hv[v] : 0.f;
-                    accb[v] += dz;
-                    acch[v] = fmaf(dst[tt], on ? c[tt][v] : 0.f, acch[v]);
-                    if (4 * g4 + v < A) zs[(16 * tt + r16) * ZS + 4 * g4 + v] = dz;
-                    q = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wd[v], dz, q, 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const bool on = c[tt][rt][v] > 0.f;
+                        float dz = on ? ds[tt] * o.hv[rt][v] : 0.f;
+                        accb[rt][v] += dz;
+                        acch[rt][v] = fmaf(ds[tt], afm_relu(c[tt][rt][v]), acch[rt][v]);
+                        if (rt == M::GRT && v == M::GV) dz = g4 == M::GA ? ago[tt] : dz;     // row A of dZ^T
+                        zsT[(16 * rt + 4 * g4 + v) * RS + 16 * tt + r16] = dz;
+                        q[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.wd[rt][v], dz, q[tt], 0, 0, 0);
+                    }
                 }
-                cd[tt] = q;
             }
             __builtin_amdgcn_wave_barrier();
+            // dWx += dZ^T . P over this round's pair slots
 #pragma unroll
-            for (int h4 = 0; h4 < 4 * NT; h4 += 4) {               // the four k-steps of a tile's pair slots at a time
-                float av[4], bv[4];
+            for (int rt = 0; rt < M::RT; ++rt) {
+                float av[NS], bv[NS];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    const int pl = 4 * (h4 + s4) + g4;
-                    av[s4] = r16 < A ? zs[pl * ZS + r16] : 0.f;
-                    bv[s4] = r16 < D ? ps[pl * PS + r16] : 0.f;
+                for (int c4 = 0; c4 < NT; ++c4) {
+                    const float4 x = *reinterpret_cast<const float4*>(zsT + (16 * rt + r16) * RS + NS * g4 + 4 * c4);
+                    const float4 y = *reinterpret_cast<const float4*>(psT + r16 * RS + NS * g4 + 4 * c4);
+                    av[4 * c4] = x.x; av[4 * c4 + 1] = x.y; av[4 * c4 + 2] = x.z; av[4 * c4 + 3] = x.w;
+                    bv[4 * c4] = y.x; bv[4 * c4 + 1] = y.y; bv[4 * c4 + 2] = y.z; bv[4 * c4 + 3] = y.w;
                 }
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) accW = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4], accW, 0, 0, 0);
+                for (int s4 = 0; s4 < NS; ++s4) accW[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bv[s4], accW[rt], 0, 0, 0);
             }
-            __builtin_amdgcn_wave_barrier();                       // p has been consumed: its rows now take dL/dp
+            // q = dL/dp of the pair, dims 4*g4 + v.  Owner side into registers; partner side into the LDS copy: every
+            // field is the partner of at most one slot per round, so the read-modify-writes of a round never meet
+            // (reads first, stores after)
+            float4 cur[NT];
+            int tgt[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (4 * g4 + v < D) ps[(16 * tt + r16) * PS + 4 * g4 + v] = cd[tt][v];
+                tgt[tt] = g4 * GS + (valid[tt] ? j4[tt] : 4 * F);
+                cur[tt] = *reinterpret_cast<const float4*>(de4 + tgt[tt]);
             }
-            __builtin_amdgcn_wave_barrier();
-            float send[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) send[k] = 0.f;
-            if (lane < F) {
+            for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const float dp = fmaf(a * go, pw[k], ps[lane * PS + k]);
-                    de[k] = fmaf(dp, ep[k], de[k]);
-                    send[k] = dp * ej[k];
-                }
-            }
-            const bool take = lane < F && afm_active(src, t, F);
+                for (int k = 0; k < 4; ++k) de[tt][k] = fmaf(q[tt][k], part[tt][k], de[tt][k]);
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const float r = __shfl(send[k], src, 64);
-                if (take) de[k] += r;
-            }
+            for (int tt = 0; tt < NT; ++tt)
+                *reinterpret_cast<float4*>(de4 + tgt[tt]) =
+                    make_float4(fmaf(q[tt][0], own[tt][0], cur[tt].x), fmaf(q[tt][1], own[tt][1], cur[tt].y),
+                                fmaf(q[tt][2], own[tt][2], cur[tt].z), fmaf(q[tt][3], own[tt][3], cur[tt].w));
         }
-        if (lane < F) {
-            float4* dst = reinterpret_cast<float4*>(demb + ((long long)b * F + lane) * D);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < D / 4; ++c) dst[c] = make_float4(de[4 * c], de[4 * c + 1], de[4 * c + 2], de[4 * c + 3]);
+        for (int tt = 0; tt < NT; ++tt) {
+            const int f = 16 * tt + r16;
+            if (f < F && 4 * g4 < D) {
+                const float4 pg = *reinterpret_cast<const float4*>(de4 + g4 * GS + 4 * f);
+                *reinterpret_cast<float4*>(demb + ((long long)b * F + f) * D + 4 * g4) =
+                    make_float4(de[tt][0] + pg.x, de[tt][1] + pg.y, de[tt][2] + pg.z, de[tt][3] + pg.w);
+            }
         }
     }
     // per-wave results -> one row per workgroup (waves added in fixed order)
     __builtin_amdgcn_wave_barrier();
     float* red = sm + wv * region;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int a_ = 4 * g4 + v;
-        if (a_ < A && r16 < D) red[a_ * D + r16] = accW[v];
-        float tb = accb[v], th = acch[v];
+    for (int rt = 0; rt < M::RT; ++rt) {
 #pragma unroll
-        for (int o_ = 1; o_ < 16; o_ <<= 1) {
-            tb += __shfl_xor(tb, o_, 64);
-            th += __shfl_xor(th, o_, 64);
+        for (int v = 0; v < 4; ++v) {
+            const int a_ = 16 * rt + 4 * g4 + v;
+            if (r16 < D) {
+                if (a_ < A) red[a_ * D + r16] = accW[rt][v];
+                else if (a_ == A) red[A * D + 2 * A + r16] = accW[rt][v];          // row A of dWx = dL/dpw
+            }
+            float tb = accb[rt][v], th = acch[rt][v];
+#pragma unroll
+            for (int o_ = 1; o_ < 16; o_ <<= 1) {
+                tb += __shfl_xor(tb, o_, 64);
+                th += __shfl_xor(th, o_, 64);
+            }
+            if (a_ < A && r16 == 0) { red[A * D + a_] = tb; red[A * D + A + a_] = th; }
         }
-        if (a_ < A && r16 == 0) { red[A * D + a_] = tb; red[A * D + A + a_] = th; }
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float t = rs_wave_sum(accpw[i]);
-        if (lane == 0) red[A * D + 2 * A + i] = t;
     }
     const float tpb = rs_wave_sum(accpb);
     if (lane == 0) red[A * D + 2 * A + D] = tpb;
@@ -1920,13 +1958,20 @@ RS_AFM_NT_ALIAS(afm_bwd_mfma4, afm_bwd_mfma_kernel, 4)
 bool afm_wave_shape(int d, int A) {
     return (d == 4 || d == 8 || d == 16 || d == 32) && (A == 4 || A == 8 || A == 16) && A * d <= 256;
 }
-// Per-wave LDS floats: sample copy [F][d+1], two [F/2][64] pair arrays, the per-pair staging [64][d+1] of p
-// (+ [64][A+1] of dL/dz in the backward); at least one parameter-gradient row.
+// Per-wave LDS floats of the vector-ALU wave kernels (d = 32): sample copy [F][d+1], two [F/2][64] pair arrays, the
+// backward's per-pair staging [64][A+1 + d+1]; at least one parameter-gradient row.
 int afm_region_floats(int F, int d, int A, bool bwd) {
-    const int need = F * (d + 1) + 2 * (F / 2) * 64 + 64 * (d + 1) + (bwd ? 64 * (A + 1) : 0), np = A * d + 2 * A + d + 1;
+    const int need = F * (d + 1) + 2 * (F / 2) * 64 + (bwd ? 64 * (A + 1 + d + 1) : 0), np = A * d + 2 * A + d + 1;
     return need > np ? need : np;
 }
-// d <= 16: the matrix-core kernels (KM); d = 32: the vector-ALU wave kernels (KV).
+// Per-wave LDS floats of the matrix-core kernels (d <= 16): the sample [4][F + 1][4], and in the backward its
+// partner-side gradient, dZ^T [16 * row tiles][16*NT + 4] and P^T [16][16*NT + 4]; at least one parameter-gradient
+// row; a multiple of 4 floats (16-byte accesses).
+int afm_mx_region_floats(int F, int d, int A, bool bwd) {
+    const int nt = F <= 48 ? 3 : 4, rs = 16 * nt + 4, rt = (A + 1 + 15) / 16;
+    const int need = 16 * (F + 1) * (bwd ? 2 : 1) + (bwd ? (16 * rt + 16) * rs : 0), np = A * d + 2 * A + d + 1;
+    return ((need > np ? need : np) + 3) & ~3;
+}
 #define RS_AFM_CASE(K, DD, AA) case (DD) * 100 + (AA): K(DD, AA); break;
 #define RS_AFM_DISPATCH(KM, KV)                                                                    \
     switch (d * 100 + A) {                                                                         \
@@ -2233,7 +2278,7 @@ int rs_afm_fwd(const float* emb, int B, int F, int d, int A, const float* W, con
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(emb && W && bA && h && pw && pb && out, "rs_afm_fwd: null argument");
     if (F <= 64 && afm_wave_shape(d, A) && (reinterpret_cast<uintptr_t>(emb) & 15) == 0) {
-        const int region = afm_region_floats(F, d, A, false);
+        const int region = d <= 16 ? afm_mx_region_floats(F, d, A, false) : afm_region_floats(F, d, A, false);
         const int wgrid = rs_cdiv(B, 4) < 2048 ? rs_cdiv(B, 4) : 2048;
 #define RS_AFM_FW(KERN, DD, AA)                                                                                        \
     do {                                                                                                               \
@@ -2280,7 +2325,7 @@ int rs_afm_bwd(const float* emb, const float* dout, int B, int F, int d, int A, 
     RS_CHECK_ARG(emb && dout && W && bA && h && pw && demb && partials, "rs_afm_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_afm_bwd: partials must have %d rows", rs_interact_partial_rows(B));
     if (F <= 64 && afm_wave_shape(d, A) && ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(demb)) & 15) == 0) {
-        const int region = afm_region_floats(F, d, A, true);
+        const int region = d <= 16 ? afm_mx_region_floats(F, d, A, true) : afm_region_floats(F, d, A, true);
         RS_CHECK_ARG((size_t)4 * region * sizeof(float) <= LDS_BIG, "rs_afm_bwd: F=%d d=%d A=%d does not fit the LDS staging", F, d, A);
 #define RS_AFM_BW(KERN, DD, AA)                                                                                        \
     do {                                                                                                               \
