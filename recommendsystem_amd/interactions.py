@@ -157,9 +157,14 @@ def nfm_bi_interaction(emb_flat: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
 # AFM
 # -------------------------------------------------------------------------------------------------
 class _AFMFn(torch.autograd.Function):
+    """Inside a trainer the five parameters are neighbouring views of its flat buffers, in the order the kernel
+    leaves their gradients in: those then land in the flat gradient buffer directly (no per-parameter accumulation
+    launch)."""
+
     @staticmethod
     def forward(ctx, emb, W, bA, h, pw, pb):
         emb = emb.contiguous()
+        ctx.pids = [id(t) for t in (W, bA, h, pw, pb)]
         args = [t.contiguous() for t in (W, bA, h, pw, pb)]
         ctx.save_for_backward(emb, *args)
         ctx.shapes = (h.shape, pw.shape)
@@ -168,6 +173,16 @@ class _AFMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         emb, W, bA, h, pw, pb = ctx.saved_tensors
+        cap = Fn.TableCapture.active
+        if cap is not None and cap.grad_sinks:
+            peek = [cap.grad_sinks.get(pid) for pid in ctx.pids]
+            if all(t is not None for t in peek) and not any(pid in cap._sunk for pid in ctx.pids) and _end_to_end(peek):
+                for pid in ctx.pids:
+                    cap.sink(pid)
+                n = sum(t.numel() for t in peek)
+                g_out = torch.as_strided(peek[0].view(-1), (n,), (1,))
+                demb = ops.afm_bwd(emb, g.contiguous().view(-1), W, bA, h, pw, g_out=g_out)[0]
+                return demb, None, None, None, None, None
         demb, dW, dbA, dh, dpw, dpb = ops.afm_bwd(emb, g.contiguous().view(-1), W, bA, h, pw)
         return demb, dW, dbA, dh.view(ctx.shapes[0]), dpw.view(ctx.shapes[1]), dpb
 

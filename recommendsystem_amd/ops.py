@@ -1094,18 +1094,20 @@ def afm_fwd(emb, W, bA, h, pw, pb) -> torch.Tensor:
     return out
 
 
-def afm_bwd(emb, dout, W, bA, h, pw):
-    """-> (demb, dW [A,d], dbA [A], dh [A], dpw [d], dpb [1])."""
+def afm_bwd(emb, dout, W, bA, h, pw, g_out=None):
+    """-> (demb, dW [A,d], dbA [A], dh [A], dpw [d], dpb [1]); g_out: optional [A*d + 2A + d + 1] destination of the five
+    parameter gradients laid end to end in that order."""
     B, Fn, d = emb.shape
     A = W.shape[0]
     _chk(dout, torch.float32, "dout", (B,))
     rows = interact_partial_rows(B)
     np_ = A * d + 2 * A + d + 1
+    _chk(g_out, torch.float32, "g_out", (np_,))
     demb = torch.empty_like(emb)
     part = torch.empty((rows, np_), dtype=torch.float32, device=emb.device)
     call("rs_afm_bwd", ptr(emb), ptr(dout), B, Fn, d, A, ptr(W), ptr(bA), ptr(h), ptr(pw), ptr(demb), ptr(part), rows,
          stream())
-    g = colsum(part)
+    g = colsum(part, out=g_out)
     o = A * d
     return demb, g[:o].view(A, d), g[o:o + A], g[o + A:o + 2 * A], g[o + 2 * A:o + 2 * A + d], g[o + 2 * A + d:]
 
