@@ -80,10 +80,12 @@ def test_row_sets_and_row_grads(B, vocabs, d):
     assert torch.equal(grad, grad2)
 
 
-@pytest.mark.parametrize("B", [4097, 5000, 7000, 8192, 8193, 12345, 16384])
+@pytest.mark.parametrize("B", [1025, 1500, 2048, 2049, 3000, 3073, 4095, 4096, 4097, 5000, 7000, 8192, 8193, 12345, 16384])
 def test_two_level_sort_writes_the_same_plan(B):
-    """Lists of more than 4096 entries are sorted as tiles and merged: the plan must equal the one-pass sort's
-    bit for bit (stable order, same chunks and segments), also beside the gather."""
+    """Lists of more than 1024 entries are sorted as tiles and merged (up to 4096 entries in one launch, the workgroup
+    of a field that finishes last doing the merge; beyond, in three launches): the plan must equal the one-pass
+    sort's bit for bit (stable order, same chunks and segments), also beside the gather and beside the Adam
+    catch-up, and again on a second call (the arrival counters reset themselves)."""
     from recommendsystem_amd import _lib, ops
     vocabs = [3, 40, 5000, 1 << 20, 2_000_000_000]
     idx, g = _case(B, vocabs, seed=B)
@@ -115,6 +117,26 @@ def test_two_level_sort_writes_the_same_plan(B):
     assert torch.equal(p.plan[:tiles_off], one.plan[:tiles_off])
     rows = (idx + torch.tensor(layout.row_offsets)[:, None]).t().to(dev)
     assert torch.equal(out["emb"], table[rows])
+    del table, out
+    two.sort_columnar(idx.to(dev))            # a second call on the same plan
+    assert torch.equal(one.plan[:tiles_off], two.plan[:tiles_off])
+    # beside the catch-up (nothing to replay at step 0), twice on the same plan; the first four fields only (three
+    # more copies of the two-billion-row table would not fit)
+    F4 = 4
+    lay4 = ops.FieldLayout(vocabs[:F4], dev)
+    idx4 = idx[:F4].contiguous().to(dev)
+    one4 = ops.SparsePlan(lay4, cap=cap, d=16, with_lr=False)
+    so4, sc4, pb4 = torch.cat([f32[:F4] * B, z[:F4]]), torch.cat([torch.full_like(f32[:F4], B), z[:F4]]), torch.cat([f32[:F4], z[:F4]])
+    _lib.call("rs_sparse_bwd_sort", _lib.ptr(idx4), _lib.ptr(so4), _lib.ptr(sc4), _lib.ptr(pb4), F4, 2, F4,
+              cap, B, one4.CHUNK, _lib.ptr(lay4.vocab_t), _lib.ptr(lay4.row_offset_t), _lib.ptr(one4.plan), _lib.stream())
+    w4 = torch.randn(lay4.total_rows, 16, device=dev)
+    hyper, step = ops.make_hyper(dev, 1e-3), torch.zeros(1, dtype=torch.int64, device=dev)
+    rs = ops.RowAdam(w4, torch.zeros_like(w4), torch.zeros_like(w4), "Adam", hyper, step)
+    q = ops.SparsePlan(lay4, cap=cap, d=16, with_lr=False)
+    off4 = F4 * (6 * cap + 6)
+    for _ in range(2):
+        q.sort_and_catchup(idx4, rs, None)
+        assert torch.equal(q.plan[:off4], one4.plan[:off4])
 
 
 def test_merge_reports_lists_longer_than_it_was_sized_for():
