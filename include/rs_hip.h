@@ -201,6 +201,26 @@ int rs_pnn_outer_fwd_range(const float* emb, int B, int F, int d, int i_lo, int 
                            rs_stream_t stream);
 int rs_pnn_outer_bwd_range(const float* emb, const float* dout, long long ld, int B, int F, int d, int i_lo, int i_hi,
                            int accumulate, float* demb, rs_stream_t stream);
+/* The first MLP layer of PNN over [x_other | outer products of all pairs] (model/PNN/PNN.py:19-27,58 fed by
+ * PNN.py:80-103) without the (B, P*d*d) matrix of products:
+ *   fwd  z[B,N] = [x_other | outer(emb)] W^T + bias        W is nn.Linear's weight [N, K0 + P*d*d], x_other [B,K0]
+ *                                                           (row stride ldx; K0 = 0: none), emb [B,F,d]
+ *   bwd  dW [N, K0 + P*d*d], db [N] (optional), demb [B,F,d], dx_other [B,K0] (optional) from dz [B,N]
+ * The reduction dimension is walked a block of pairs at a time (rs_pnn_outer_fwd_range into a cache-sized buffer,
+ * rs_gemm_f32_acc into the running sum); the backward recomputes each block.  workspace: 16-byte aligned device
+ * memory of rs_pnn_outer_mlp_workspace_floats(B, F, d, K0, N, backward) floats (aligned copies of W and x_other, the
+ * block buffers, split-K scratch; for the backward also dW in the aligned layout); nothing is kept between the two
+ * calls.  block_bytes: size aimed at for one block of products (<= 0: 192 MiB, which stays in the 256 MB Infinity
+ * Cache); rs_pnn_outer_mlp_blocks tells how many blocks that makes.  Activation, normalisation and dropout of the
+ * MLPBlock are applied to z by the caller. */
+size_t rs_pnn_outer_mlp_workspace_floats(int B, int F, int d, int K0, int N, int backward, long long block_bytes);
+int rs_pnn_outer_mlp_blocks(int B, int F, int d, long long block_bytes);
+int rs_pnn_outer_mlp_fwd(const float* emb, const float* x_other, long long ldx, int B, int F, int d, int K0, const float* W,
+                         const float* bias, int N, float* z, float* workspace, size_t workspace_floats,
+                         long long block_bytes, rs_stream_t stream);
+int rs_pnn_outer_mlp_bwd(const float* emb, const float* x_other, long long ldx, const float* dz, int B, int F, int d, int K0,
+                         const float* W, int N, float* dW, float* db, float* demb, float* dx_other, float* workspace,
+                         size_t workspace_floats, long long block_bytes, rs_stream_t stream);
 
 /* DCN cross network x_{l+1} = x0 (x_l . w_l) + b_l + x_l, w/bias [L,D]; S[B,L] = x_l . w_l saved for the backward
  * (model/DCN/DCN.py:48-52, with the bias broadcast over the batch).  partials: [rows, 2*L*D] = [dW | dB]. */

@@ -105,6 +105,9 @@ _SIGS = {
     "rs_pnn_outer_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_fwd_range": [c_f32p, I, I, I, I, I, c_f32p, L, c_stream],
     "rs_pnn_outer_bwd_range": [c_f32p, c_f32p, L, I, I, I, I, I, I, c_f32p, c_stream],
+    "rs_pnn_outer_mlp_fwd": [c_f32p, c_f32p, L, I, I, I, I, c_f32p, c_f32p, I, c_f32p, c_f32p, SZ, L, c_stream],
+    "rs_pnn_outer_mlp_bwd": [c_f32p, c_f32p, L, c_f32p, I, I, I, I, c_f32p, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, SZ,
+                             L, c_stream],
     "rs_dcn_cross_fwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_dcn_cross_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
     "rs_nfm_bi_fwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
@@ -131,6 +134,8 @@ _PLAIN = {
     "rs_colsum_workspace_bytes": (SZ, [I, I]),
     "rs_colsum_noalloc_max_floats": (SZ, []),
     "rs_sort_plan_ints": (SZ, [I, I]),
+    "rs_pnn_outer_mlp_workspace_floats": (SZ, [I, I, I, I, I, I, L]),
+    "rs_pnn_outer_mlp_blocks": (I, [I, I, I, L]),
     "rs_sort_max_entries": (I, []),
     "rs_merge_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),

@@ -409,102 +409,34 @@ def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, 
 # -------------------------------------------------------------------------------------------------
 # PNN: the first MLP layer over [embeddings | inner products | outer products of all field pairs]
 # -------------------------------------------------------------------------------------------------
-OUTER_BLOCK_BYTES = 192 << 20        # size aimed at for one block of outer products (stays in the 256 MB Infinity Cache)
-
-
-def outer_blocks(Fn: int, d: int, B: int):
-    """[(i_lo, i_hi)]: ranges of the first field of a pair whose products [B, n_pairs*d*d] fill about
-    OUTER_BLOCK_BYTES (a range holds at least one field; pairs are numbered first field major)."""
-    budget = max(1, OUTER_BLOCK_BYTES // (B * d * d * 4))
-    blocks, lo = [], 0
-    while lo < Fn - 1:
-        hi, n = lo + 1, Fn - 1 - lo
-        while hi < Fn - 1 and n + (Fn - 1 - hi) <= budget:
-            n += Fn - 1 - hi
-            hi += 1
-        blocks.append((lo, hi))
-        lo = hi
-    return blocks
+OUTER_BLOCK_BYTES = 0                # size aimed at for one block of outer products; 0: the library's 192 MiB
 
 
 class OuterLinear:
     """z = [x_other | outer(emb)] W^T + b without the (B, P*d*d) matrix of outer products (model/PNN/PNN.py:80-103
-    feeding PNN.py:19-27,58: 189,696 columns at F = 39, d = 16, 3.1 GB at B = 4096): the reduction dimension is walked a
-    block of pairs at a time -- products of the block written, multiplied into the running sum (rs_gemm_f32_acc),
-    buffer reused -- and the backward recomputes each block to form its columns of dW and its share of demb.  W's rows
-    (K0 + P*d*d floats, not a multiple of four) are first copied into a shadow whose two column groups start 16-byte
-    aligned, so every product runs on the DMA GEMM; dW is built in the same layout and copied back."""
+    feeding PNN.py:19-27,58: 189,696 columns at F = 39, d = 16, 3.1 GB at B = 4096).  The library walks the reduction
+    dimension a block of pairs at a time (rs_pnn_outer_mlp_fwd / _bwd: products of the block written to a cache-sized
+    buffer, multiplied into the running sum, buffer reused; the backward recomputes each block to form its columns
+    of dW and its share of demb)."""
 
     def __init__(self, emb, x_other, W, b):
         self.emb = emb.contiguous()                       # [B, F, d]
         B, Fn, d = self.emb.shape
-        self.B, self.F, self.d = B, Fn, d
-        self.dd = d * d
-        self.K0 = 0 if x_other is None else x_other.shape[1]
-        self.K0p = (self.K0 + 3) // 4 * 4
-        self.KO = Fn * (Fn - 1) // 2 * self.dd
-        if W.shape[1] != self.K0 + self.KO:
-            raise ops.RSError(f"OuterLinear: weight has {W.shape[1]} columns, expected {self.K0} + {self.KO}")
-        self.W, self.b = W, b
-        self.blocks = outer_blocks(Fn, d, B)
-        self.wmax = max((ops.pair_start(hi, Fn) - ops.pair_start(lo, Fn)) * self.dd for lo, hi in self.blocks)
-        self.x_other = x_other
-        self.xo = self.Ws = None
-
-    def _cols(self, lo, hi):
-        off = self.K0p + ops.pair_start(lo, self.F) * self.dd
-        return off, (ops.pair_start(hi, self.F) - ops.pair_start(lo, self.F)) * self.dd
+        K0 = 0 if x_other is None else x_other.shape[1]
+        KO = Fn * (Fn - 1) // 2 * d * d
+        if W.shape[1] != K0 + KO:
+            raise ops.RSError(f"OuterLinear: weight has {W.shape[1]} columns, expected {K0} + {KO}")
+        if x_other is not None and x_other.stride(-1) != 1:
+            x_other = x_other.contiguous()
+        self.x_other, self.W, self.b = x_other, W, b
 
     def forward(self):
-        W, N = self.W.detach(), self.W.shape[0]
-        Ws = torch.empty((N, self.K0p + self.KO), dtype=torch.float32, device=W.device)
-        if self.K0:
-            Ws[:, :self.K0].copy_(W[:, :self.K0])
-            if self.K0p > self.K0:
-                Ws[:, self.K0:self.K0p].zero_()
-        Ws[:, self.K0p:].copy_(W[:, self.K0:])
-        self.Ws = Ws
-        z = torch.empty((self.B, N), dtype=torch.float32, device=W.device)
-        started = False
-        if self.K0:
-            xo = self.x_other
-            if self.K0p > self.K0 or not xo.is_contiguous():
-                xo = _pad_columns(xo, self.K0p - self.K0) if self.K0p > self.K0 else xo.contiguous()
-            self.xo = xo
-            ops.gemm(xo, Ws[:, :self.K0p], out=z)
-            started = True
-        buf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=W.device)
-        for k, (lo, hi) in enumerate(self.blocks):
-            off, w = self._cols(lo, hi)
-            Xb = ops.pnn_outer_fwd_range(self.emb, lo, hi, out=buf[:, :w])
-            last = k == len(self.blocks) - 1
-            ops.gemm(Xb, Ws[:, off:off + w], out=z, accumulate=started, bias=self.b.detach() if last else None)
-            started = True
-        return z
+        return ops.pnn_outer_mlp_fwd(self.emb, self.x_other, self.W.detach().contiguous(), self.b.detach(),
+                                     block_bytes=OUTER_BLOCK_BYTES)
 
     def backward(self, dz, dW_out=None, db_out=None):
-        Ws, N = self.Ws, self.W.shape[0]
-        dev = dz.device
-        dWs = torch.empty_like(Ws)
-        dxo = None
-        if self.K0:
-            ops.gemm(dz, self.xo, a_mc=True, b_nc=True, out=dWs[:, :self.K0p])
-            dxo = ops.gemm(dz, Ws[:, :self.K0p], b_nc=True)[:, :self.K0]
-        demb = torch.empty_like(self.emb)
-        buf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=dev)
-        gbuf = torch.empty((self.B, self.wmax), dtype=torch.float32, device=dev)
-        for k, (lo, hi) in enumerate(self.blocks):
-            off, w = self._cols(lo, hi)
-            Xb = ops.pnn_outer_fwd_range(self.emb, lo, hi, out=buf[:, :w])
-            ops.gemm(dz, Xb, a_mc=True, b_nc=True, out=dWs[:, off:off + w])
-            G = ops.gemm(dz, Ws[:, off:off + w], b_nc=True, out=gbuf[:, :w])
-            ops.pnn_outer_bwd_range(self.emb, G, lo, hi, demb, accumulate=k > 0)
-        dW = dW_out if dW_out is not None else torch.empty_like(self.W)
-        if self.K0:
-            dW[:, :self.K0].copy_(dWs[:, :self.K0])
-        dW[:, self.K0:].copy_(dWs[:, self.K0p:])
-        db = ops.colsum(dz, out=db_out)
-        self.Ws = self.xo = None
+        dW, db, demb, dxo = ops.pnn_outer_mlp_bwd(self.emb, self.x_other, dz.contiguous(), self.W.detach().contiguous(),
+                                                  dW_out=dW_out, db_out=db_out, block_bytes=OUTER_BLOCK_BYTES)
         return {"dx": None, "dW": dW, "db": db, "demb": demb, "dx_other": dxo}
 
 

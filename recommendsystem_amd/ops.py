@@ -1029,6 +1029,50 @@ def pnn_outer_bwd_range(emb: torch.Tensor, dout: torch.Tensor, i_lo: int, i_hi: 
     return demb
 
 
+def pnn_outer_mlp_fwd(emb, x_other, W, bias, block_bytes: int = 0, ws: Optional[Workspace] = None) -> torch.Tensor:
+    """z = [x_other | outer products of all field pairs of emb] W^T + bias without the matrix of products (a block of
+    pairs at a time inside the library; block_bytes: size of a block of products, 0 = the library's default).
+    emb [B,F,d]; x_other [B,K0] (rows contiguous) or None; W [N, K0 + P*d*d]."""
+    B, Fn, d = emb.shape
+    N = W.shape[0]
+    K0 = 0 if x_other is None else x_other.shape[1]
+    _chk(emb, torch.float32, "emb")
+    _chk(W, torch.float32, "W", (N, K0 + Fn * (Fn - 1) // 2 * d * d))
+    _chk(bias, torch.float32, "bias", (N,))
+    ldx = _chk_rows(x_other, "x_other", (B, K0)) if x_other is not None else 0
+    n = _lib.lib().rs_pnn_outer_mlp_workspace_floats(B, Fn, d, K0, N, 0, int(block_bytes))
+    if n == 0:
+        raise RSError("pnn_outer_mlp: unsupported shape")
+    wbuf = (ws or default_workspace(emb.device)).get("pnn_outer_mlp", n)
+    z = torch.empty((B, N), dtype=torch.float32, device=emb.device)
+    call("rs_pnn_outer_mlp_fwd", ptr(emb), ptr(x_other), ldx, B, Fn, d, K0, ptr(W), ptr(bias), N, ptr(z), ptr(wbuf), n,
+         int(block_bytes), stream())
+    return z
+
+
+def pnn_outer_mlp_bwd(emb, x_other, dz, W, dW_out=None, db_out=None, want_dx_other=True, block_bytes: int = 0,
+                      ws: Optional[Workspace] = None):
+    """-> (dW [N, K0 + P*d*d], db [N], demb [B,F,d], dx_other [B,K0] or None) of pnn_outer_mlp_fwd."""
+    B, Fn, d = emb.shape
+    N = W.shape[0]
+    K0 = 0 if x_other is None else x_other.shape[1]
+    _chk(dz, torch.float32, "dz", (B, N))
+    ldx = _chk_rows(x_other, "x_other", (B, K0)) if x_other is not None else 0
+    n = _lib.lib().rs_pnn_outer_mlp_workspace_floats(B, Fn, d, K0, N, 1, int(block_bytes))
+    if n == 0:
+        raise RSError("pnn_outer_mlp: unsupported shape")
+    wbuf = (ws or default_workspace(emb.device)).get("pnn_outer_mlp", n)
+    dW = dW_out if dW_out is not None else torch.empty_like(W)
+    db = db_out if db_out is not None else torch.empty((N,), dtype=torch.float32, device=emb.device)
+    _chk(dW, torch.float32, "dW", tuple(W.shape))
+    _chk(db, torch.float32, "db", (N,))
+    demb = torch.empty_like(emb)
+    dxo = torch.empty((B, K0), dtype=torch.float32, device=emb.device) if (K0 and want_dx_other) else None
+    call("rs_pnn_outer_mlp_bwd", ptr(emb), ptr(x_other), ldx, ptr(dz), B, Fn, d, K0, ptr(W), N, ptr(dW), ptr(db), ptr(demb),
+         ptr(dxo), ptr(wbuf), n, int(block_bytes), stream())
+    return dW, db, demb, dxo
+
+
 def dcn_cross_fwd(x0: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     """x0 [B,D]; w, bias [L,D] -> (out [B,D], S [B,L])."""
     _chk(x0, torch.float32, "x0")

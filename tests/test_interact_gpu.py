@@ -327,14 +327,17 @@ def test_pnn_outer_pair_ranges(B, F, d):
                                                  (True, "ln", "leakyrelu")])
 def test_pnn_first_block_in_pair_blocks(with_other, norm, act, monkeypatch):
     """functional.pnn_outer_block (the first MLP layer of PNN over [x_other | outer products], a block of pairs at a
-    time, weights in an aligned shadow) against the same MLPBlock applied to the materialised concatenation
-    (PNN.py:58), forward and every gradient; the block size is forced down so that the pairs fall into several blocks."""
+    time, weights in an aligned shadow: rs_pnn_outer_mlp_fwd / _bwd) against the same MLPBlock applied to the
+    materialised concatenation (PNN.py:58), forward and every gradient; the block size is forced down so that the
+    pairs fall into several blocks."""
+    from recommendsystem_amd import _lib
     from recommendsystem_amd import functional as Fn
     from recommendsystem_amd import interactions as X
     from recommendsystem_amd import layers
     B, F, d, N = 96, 7, 4, 24
     monkeypatch.setattr(Fn, "OUTER_BLOCK_BYTES", B * d * d * 4 * 6)          # 6 pairs per block at most
-    assert len(Fn.outer_blocks(F, d, B)) >= 3
+    assert _lib.lib().rs_pnn_outer_mlp_blocks(B, F, d, Fn.OUTER_BLOCK_BYTES) >= 3
+    assert _lib.lib().rs_pnn_outer_mlp_blocks(B, F, d, 0) == 1
     torch.manual_seed(11)
     K0 = F * d + 5 if with_other else 0                                      # an odd width in front of the products
     KO = F * (F - 1) // 2 * d * d
