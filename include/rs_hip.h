@@ -191,6 +191,15 @@ int rs_interact_partial_rows(int B);
 /* PNN inner products <e_i,e_j> -> out[B,P]                       (model/PNN/PNN.py:65-77) */
 int rs_pnn_inner_fwd(const float* emb, int B, int F, int d, float* out, rs_stream_t stream);
 int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, rs_stream_t stream);
+/* The input row of PNN's first MLP layer with pnn_type inner, cat([emb.flatten(1), inner products], 1) (PNN.py:58),
+ * written by the product kernel itself: out [B, ld], row = [F*d embedding values | P products | zeros], ld >= F*d + P
+ * a multiple of four (the GEMM's operand alignment) with fewer than 64 columns of padding.  The backward takes the
+ * gradient of such rows (row stride ld) and returns demb = dout[:, :F*d] + the products' share.
+ * rs_pnn_inner_cat_ok: 1 when (F, d) is served (F <= 64, d in {4, 8, 16, 32}; emb and out 16-byte aligned). */
+int rs_pnn_inner_cat_ok(int F, int d);
+int rs_pnn_inner_cat_fwd(const float* emb, int B, int F, int d, float* out, long long ld, rs_stream_t stream);
+int rs_pnn_inner_cat_bwd(const float* emb, const float* dout, long long ld, int B, int F, int d, float* demb,
+                         rs_stream_t stream);
 /* PNN outer products e_i e_j^T flattened -> out[B,P*d*d]         (model/PNN/PNN.py:80-103) */
 int rs_pnn_outer_fwd(const float* emb, int B, int F, int d, float* out, rs_stream_t stream);
 int rs_pnn_outer_bwd(const float* emb, const float* dout, int B, int F, int d, float* demb, rs_stream_t stream);

@@ -101,6 +101,8 @@ _SIGS = {
     "rs_fm_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_inner_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_inner_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
+    "rs_pnn_inner_cat_fwd": [c_f32p, I, I, I, c_f32p, L, c_stream],
+    "rs_pnn_inner_cat_bwd": [c_f32p, c_f32p, L, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_fwd": [c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_bwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_stream],
     "rs_pnn_outer_fwd_range": [c_f32p, I, I, I, I, I, c_f32p, L, c_stream],
@@ -136,6 +138,7 @@ _PLAIN = {
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_pnn_outer_mlp_workspace_floats": (SZ, [I, I, I, I, I, I, L]),
     "rs_pnn_outer_mlp_blocks": (I, [I, I, I, L]),
+    "rs_pnn_inner_cat_ok": (I, [I, I]),
     "rs_sort_max_entries": (I, []),
     "rs_merge_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),

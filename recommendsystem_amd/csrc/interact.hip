@@ -131,15 +131,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Forward: lane (r, g) loads the float4 E[16I + r][4(g + 4q) ..] of every field block I (one coalesced 1 KB read per
 // block); component s of that float4 serves as the lane's k-slot of MFMA step (q, s) for the A and the B operand
 // alike (the summation index may be visited in any order as long as both operands agree).
-template <int NB, int D>
+// ld: row stride of out.  CAT: a row of out is [the sample's F*D embedding values | its P products | zeros up to ld]
+// -- the input of PNN's first MLP layer (PNN.py:58 with pnn_type inner), its width rounded up to four floats -- so
+// that neither the concatenation nor the padding needs a launch of its own.
+template <int NB, int D, bool CAT>
 __global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __restrict__ emb, int B, int F,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, long long ld) {
     constexpr int NV = D >= 16 ? D / 16 : 1;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const int nwaves = gridDim.x * 4;
     const int fd = F * D, P = F * (F - 1) / 2;
     for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
         const float* e = emb + (long long)b * fd;
+        float* orow = out + (long long)b * ld;
         float v[NB][NV][4];
 #pragma unroll
         for (int I = 0; I < NB; ++I)
@@ -147,10 +151,14 @@ __global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __
             for (int q = 0; q < NV; ++q) {
                 const int row = 16 * I + r, c = g + 4 * q;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < F && c < D / 4) t = *reinterpret_cast<const float4*>(e + row * D + 4 * c);
+                if (row < F && c < D / 4) {
+                    t = *reinterpret_cast<const float4*>(e + row * D + 4 * c);
+                    if (CAT) *reinterpret_cast<float4*>(orow + row * D + 4 * c) = t;
+                }
                 v[I][q][0] = t.x; v[I][q][1] = t.y; v[I][q][2] = t.z; v[I][q][3] = t.w;
             }
-        float* o = out + (long long)b * P;
+        if (CAT && lane < (int)(ld - fd - P)) orow[fd + P + lane] = 0.f;
+        float* o = orow + (CAT ? fd : 0);
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -174,9 +182,11 @@ __global__ __launch_bounds__(256) void pnn_inner_fwd_mfma_kernel(const float* __
 // Backward: demb = Gs E.  The sample's dP row is copied to LDS with coalesced reads; the A operand of step s, row
 // block I -- Gs[16I + r][4s + g] -- is gathered from there through pair slots that do not depend on the sample
 // (computed once per wave); B operand: E[4s + g][16c + r], straight from HBM (256 contiguous bytes per request).
-template <int NB, int D>
+// ld: row stride of dout.  CAT: a row of dout is the gradient of the concatenated row the forward writes; its first
+// F*D values are added to the result (the embeddings' own path into the MLP).
+template <int NB, int D, bool CAT>
 __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                                 int B, int F, float* __restrict__ demb) {
+                                                                 int B, int F, float* __restrict__ demb, long long ld) {
     extern __shared__ float sm[];
     constexpr int KS = NB * 4;
     constexpr int NC = D >= 16 ? D / 16 : 1;
@@ -195,7 +205,8 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
     if (lane == 0) gl[P] = 0.f;
     for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
         const float* e = emb + (long long)b * fd;
-        const float* gs = dout + (long long)b * P;
+        const float* drow = dout + (long long)b * ld;
+        const float* gs = drow + (CAT ? fd : 0);
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < P; i += 64) gl[i] = gs[i];
         float bv[KS][NC];
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int row = 16 * I + 4 * g + t, col = 16 * c + r;
-                    if (row < F && col < D) o[row * D + col] = acc[c][t];
+                    if (row < F && col < D) o[row * D + col] = CAT ? acc[c][t] + drow[row * D + col] : acc[c][t];
                 }
         }
     }
@@ -2053,7 +2064,7 @@ int rs_pnn_inner_fwd(const float* emb, int B, int F, int d, float* out, hipStrea
     RS_CHECK_ARG(emb && out, "rs_pnn_inner_fwd: null argument");
     if (pnn_mfma_ok(F, d, emb)) {
         const int grid = pnn_mfma_grid(B);
-#define RS_PNN_F(NB, DD) hipLaunchKernelGGL((pnn_inner_fwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), 0, stream, emb, B, F, out)
+#define RS_PNN_F(NB, DD) hipLaunchKernelGGL((pnn_inner_fwd_mfma_kernel<NB, DD, false>), dim3(grid), dim3(256), 0, stream, emb, B, F, out, (long long)(F * (F - 1) / 2))
         RS_PNN_DISPATCH(RS_PNN_F)
 #undef RS_PNN_F
         RS_CHECK_LAUNCH("rs_pnn_inner_fwd");
@@ -2073,7 +2084,7 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
     if (pnn_mfma_ok(F, d, emb)) {
         const int grid = pnn_mfma_grid(B);
         const size_t blds = (size_t)4 * (F * (F - 1) / 2 + 1) * sizeof(float);
-#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD>), dim3(grid), dim3(256), blds, stream, emb, dout, B, F, demb)
+#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD, false>), dim3(grid), dim3(256), blds, stream, emb, dout, B, F, demb, (long long)(F * (F - 1) / 2))
         RS_PNN_DISPATCH(RS_PNN_B)
 #undef RS_PNN_B
         RS_CHECK_LAUNCH("rs_pnn_inner_bwd");
@@ -2083,6 +2094,45 @@ int rs_pnn_inner_bwd(const float* emb, const float* dout, int B, int F, int d, f
     RS_CHECK_ARG(lds <= LDS_LIMIT, "rs_pnn_inner_bwd: F=%d d=%d does not fit the LDS staging", F, d);
     hipLaunchKernelGGL(pnn_inner_bwd_kernel, dim3(rs_cdiv(B, 4)), dim3(256), lds, stream, emb, dout, B, F, d, demb);
     RS_CHECK_LAUNCH("rs_pnn_inner_bwd");
+    return RS_OK;
+}
+
+// The input of PNN's first MLP layer with pnn_type inner (PNN.py:58): out [B, ld] rows = [emb row (F*d) | inner
+// products (P) | zeros], ld >= F*d + P a multiple of four with at most 63 columns of padding; the backward takes the
+// gradient of such rows and returns demb = dout[:, :F*d] + the products' share.  1 when the shape is served (the
+// matrix-core kernels: F <= 64, d in {4, 8, 16, 32}, 16-byte aligned rows), else 0.
+int rs_pnn_inner_cat_ok(int F, int d) { return pnn_mfma_ok(F, d, nullptr) ? 1 : 0; }
+
+int rs_pnn_inner_cat_fwd(const float* emb, int B, int F, int d, float* out, long long ld, hipStream_t stream) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_inner_cat_fwd: bad sizes");
+    if (B == 0) return RS_OK;
+    RS_CHECK_ARG(emb && out, "rs_pnn_inner_cat_fwd: null argument");
+    const long long K = (long long)F * d + F * (F - 1) / 2;
+    RS_CHECK_ARG(ld >= K && ld % 4 == 0 && ld - K < 64, "rs_pnn_inner_cat_fwd: row stride %lld for %lld columns", ld, K);
+    RS_CHECK_ARG(pnn_mfma_ok(F, d, emb) && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                 "rs_pnn_inner_cat_fwd: F=%d d=%d (or the alignment of emb / out) is not served", F, d);
+    const int grid = pnn_mfma_grid(B);
+#define RS_PNN_F(NB, DD) hipLaunchKernelGGL((pnn_inner_fwd_mfma_kernel<NB, DD, true>), dim3(grid), dim3(256), 0, stream, emb, B, F, out, ld)
+    RS_PNN_DISPATCH(RS_PNN_F)
+#undef RS_PNN_F
+    RS_CHECK_LAUNCH("rs_pnn_inner_cat_fwd");
+    return RS_OK;
+}
+
+int rs_pnn_inner_cat_bwd(const float* emb, const float* dout, long long ld, int B, int F, int d, float* demb,
+                         hipStream_t stream) {
+    RS_CHECK_ARG(B >= 0 && F > 1 && d > 0, "rs_pnn_inner_cat_bwd: bad sizes");
+    if (B == 0) return RS_OK;
+    RS_CHECK_ARG(emb && dout && demb, "rs_pnn_inner_cat_bwd: null argument");
+    const long long K = (long long)F * d + F * (F - 1) / 2;
+    RS_CHECK_ARG(ld >= K, "rs_pnn_inner_cat_bwd: row stride %lld for %lld columns", ld, K);
+    RS_CHECK_ARG(pnn_mfma_ok(F, d, emb), "rs_pnn_inner_cat_bwd: F=%d d=%d (or the alignment of emb) is not served", F, d);
+    const int grid = pnn_mfma_grid(B);
+    const size_t blds = (size_t)4 * (F * (F - 1) / 2 + 1) * sizeof(float);
+#define RS_PNN_B(NB, DD) hipLaunchKernelGGL((pnn_inner_bwd_mfma_kernel<NB, DD, true>), dim3(grid), dim3(256), blds, stream, emb, dout, B, F, demb, ld)
+    RS_PNN_DISPATCH(RS_PNN_B)
+#undef RS_PNN_B
+    RS_CHECK_LAUNCH("rs_pnn_inner_cat_bwd");
     return RS_OK;
 }
 

@@ -203,7 +203,7 @@ def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
 # -------------------------------------------------------------------------------------------------
 class MLPCtx:
     __slots__ = ("x", "W", "h", "z", "y", "xhat", "var", "rstd", "act", "norm", "gamma", "slope", "eps", "k", "one",
-                 "linear", "drop_fused")
+                 "linear", "drop_fused", "pre")
 
 
 def _pad_columns(t, pad: int):
@@ -218,7 +218,9 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
                   running_mean=None, running_var=None, eps=1e-5, allow_pad=False, linear=None, dropout=None):
     """act(norm(x W^T + b)) for one block (Layers.py:39-47).  Returns (h, ctx).
 
-    allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width).
+    allow_pad: the caller's backward is mlp_block_bwd (which knows about a padded input width).  x2d may come in
+    padded already (zero columns up to the next multiple of four behind W's input width: pnn_inner_input); its
+    gradient then keeps that width.
     linear: an object whose forward() returns x W^T + b and whose backward(dz) returns dict(dx, dW, db) in place of the
     plain GEMMs (OuterLinear: an input too wide to exist at once); x2d is then ignored.
     dropout: the (p, seed, salt, call_no, call_dev) key of the block's dropout.  Where the mask can ride in the GEMM's
@@ -230,6 +232,9 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
     c.k = W.shape[1]
     c.linear = linear
     c.drop_fused = False
+    c.pre = linear is None and x2d.shape[1] != c.k
+    if c.pre and not (allow_pad and x2d.shape[1] == (c.k + 3) // 4 * 4):
+        raise ops.RSError(f"mlp_block: input has {x2d.shape[1]} columns, the weight {c.k}")
     if linear is not None:
         c.one = False
         z = linear.forward()
@@ -255,11 +260,13 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
         return c.h, c
     # a 1-wide plain layer is a dot product per row, not a GEMM
     c.one = (W.shape[0] == 1 and not norm and act in _FUSABLE and b is not None and W.shape[1] <= _ONE_WIDE_MAX_K
-             and (W.shape[1] % 4 != 0 or (x2d.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)))
+             and not c.pre and (W.shape[1] % 4 != 0 or (x2d.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)))
     if c.one:
         c.h = ops.rowdot_fwd(x2d, W.reshape(-1), b, act).view(-1, 1)
         return c.h, c
-    if allow_pad and c.k % 4 != 0 and c.k >= _PAD_MIN_K and x2d.shape[0] >= 256:
+    if c.pre:
+        c.W = W = _pad_columns(W.detach(), x2d.shape[1] - c.k)
+    elif allow_pad and c.k % 4 != 0 and c.k >= _PAD_MIN_K and x2d.shape[0] >= 256:
         # rows of an odd width are not 16-byte aligned and would take the register-staged GEMM; zero columns up to
         # the next multiple of four change no sum and let all three products of the block run on the DMA kernel
         c.x = x2d = _pad_columns(x2d, 4 - c.k % 4)
@@ -350,7 +357,11 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             out["dW"] = dWp[:, :c.k]
         if not db_done:
             out["db"] = ops.colsum(dz, out=db_out)
-        out["dx"] = ops.gemm(dz, c.W, b_nc=True)[:, :c.k] if need_dx else None
+        out["dx"] = None
+        if need_dx:
+            out["dx"] = ops.gemm(dz, c.W, b_nc=True)
+            if not c.pre:
+                out["dx"] = out["dx"][:, :c.k]
         if need_dx and mulsrc is not None:
             out["dx"] = ops.act_bwd(out["dx"].contiguous(), mul_act, h=mulsrc)[0]
         out["dz"] = dz
@@ -475,6 +486,33 @@ def pnn_outer_block(block, emb, x_other):
     h = _PNNOuterBlockFn.apply(emb, x_other, block.fc.weight, block.fc.bias, gamma, beta, slope, block._act,
                                block.normalization or None, block.training, rm, rv, eps)
     return block.dropout(h)
+
+
+class _PNNInnerInputFn(torch.autograd.Function):
+    """cat([emb.flatten(1), inner products of all field pairs], 1) (model/PNN/PNN.py:58 with pnn_type inner, the
+    products of PNN.py:65-77), zero columns up to the next multiple of four behind it: written by the product kernel in
+    one launch, and its backward returns the embeddings' gradient through both paths at once."""
+
+    @staticmethod
+    def forward(ctx, emb):
+        emb = emb.contiguous()
+        ctx.save_for_backward(emb)
+        return ops.pnn_inner_cat_fwd(emb)
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, = ctx.saved_tensors
+        if g.stride(-1) != 1:
+            g = g.contiguous()
+        return ops.pnn_inner_cat_bwd(emb, g)
+
+
+def pnn_inner_input(emb):
+    """The (padded) input of PNN's first MLP layer for pnn_type inner, or None when the shape is not served by the
+    concatenating kernel (the caller then concatenates itself)."""
+    if emb.dim() != 3 or not emb.is_cuda or emb.dtype != torch.float32 or not ops.pnn_inner_cat_ok(emb.shape[1], emb.shape[2]):
+        return None
+    return _PNNInnerInputFn.apply(emb)
 
 
 _dropout_calls = 0

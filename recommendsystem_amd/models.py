@@ -217,7 +217,12 @@ class PNN(_CTRModel):
         emb_out = self.embedding_layer(x)
         flat = emb_out.view(emb_out.shape[0], -1)
         if self.pnn_type == "inner":
-            return self.mlp(torch.cat([flat, self.inner_product(emb_out)], dim=1))
+            # one launch writes [embeddings | inner products | zeros up to a multiple of four columns]; the first block
+            # takes the padded rows as they are (functional.mlp_block_fwd)
+            xin = Fn.pnn_inner_input(emb_out)
+            if xin is None:
+                xin = torch.cat([flat, self.inner_product(emb_out)], dim=1)
+            return self.mlp(xin)
         # The outer products are 741 * 256 values per sample at F = 39, d = 16: the first block takes them a block of
         # pairs at a time (functional.OuterLinear) instead of reading cat([flat, pnn_output]) (PNN.py:58); the columns
         # of its weight keep the reference's order [embeddings | inner | outer].

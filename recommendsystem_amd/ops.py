@@ -998,6 +998,33 @@ def pnn_outer_bwd(emb: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     return demb
 
 
+def pnn_inner_cat_ok(Fn: int, d: int) -> bool:
+    return bool(_lib.lib().rs_pnn_inner_cat_ok(int(Fn), int(d)))
+
+
+def pnn_inner_cat_fwd(emb: torch.Tensor) -> torch.Tensor:
+    """[B, ceil4(F*d + P)] rows = [emb row | inner products of all field pairs | zeros]: the (padded) input of PNN's
+    first MLP layer with pnn_type inner, in one launch."""
+    B, Fn, d = emb.shape
+    _chk(emb, torch.float32, "emb")
+    K = Fn * d + Fn * (Fn - 1) // 2
+    ld = (K + 3) // 4 * 4
+    out = torch.empty((B, ld), dtype=torch.float32, device=emb.device)
+    call("rs_pnn_inner_cat_fwd", ptr(emb), B, Fn, d, ptr(out), ld, stream())
+    return out
+
+
+def pnn_inner_cat_bwd(emb: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    """demb of pnn_inner_cat_fwd from the gradient of its rows."""
+    B, Fn, d = emb.shape
+    ld = _chk_rows(dout, "dout")
+    if dout.shape[0] != B or dout.shape[1] < Fn * d + Fn * (Fn - 1) // 2:
+        raise RSError("pnn_inner_cat_bwd: dout does not hold the concatenated rows")
+    demb = torch.empty_like(emb)
+    call("rs_pnn_inner_cat_bwd", ptr(emb), ptr(dout), ld, B, Fn, d, ptr(demb), stream())
+    return demb
+
+
 def pair_start(i: int, F: int) -> int:
     """Index of pair (i, i+1) in the first-field-major numbering of the F(F-1)/2 pairs (PNN.py:83-85)."""
     return i * (2 * F - i - 1) // 2

@@ -370,3 +370,25 @@ def test_pnn_first_block_in_pair_blocks(with_other, norm, act, monkeypatch):
     for k in g_ref:
         atol = 1e-4 if (k == "fc.bias" and norm) else 2e-5 * max(1.0, float(g_ref[k].abs().max()))
         close(g[k], g_ref[k], rtol=1e-4, atol=atol, msg=k)
+
+
+@pytest.mark.parametrize("B,Fn,d", [(3, 2, 4), (70, 7, 8), (300, 26, 16), (260, 39, 16), (33, 64, 4), (5, 8, 4), (9, 17, 32)])
+def test_pnn_inner_input_rows(B, Fn, d):
+    """functional.pnn_inner_input (the product kernel writes [embeddings | inner products | zero padding] itself,
+    PNN.py:58,65-77) against cat([emb.flatten(1), oracle inner products]) and its gradient through both paths."""
+    from recommendsystem_amd import functional as F_
+    g = torch.Generator().manual_seed(B * 7 + Fn)
+    emb = torch.randn(B, Fn, d, generator=g)
+    K = Fn * d + Fn * (Fn - 1) // 2
+    er = emb.clone().requires_grad_(True)
+    ref = torch.cat([er.flatten(1), O.pnn_inner(er.flatten(1), Fn, d)], 1)
+    gout = torch.randn(B, (K + 3) // 4 * 4, generator=g)
+    (ref * gout[:, :K]).sum().backward()
+    eg = emb.to(DEV).requires_grad_(True)
+    x = F_.pnn_inner_input(eg)
+    assert x is not None and x.shape == (B, (K + 3) // 4 * 4)
+    assert torch.equal(x[:, :Fn * d].cpu(), emb.flatten(1))                  # the copy is exact
+    assert (x[:, K:] == 0).all()
+    close(x[:, Fn * d:K], ref[:, Fn * d:].detach(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()), msg="products")
+    (x * gout.to(DEV)).sum().backward()
+    close(eg.grad, er.grad, rtol=1e-5, atol=1e-5 * float(er.grad.abs().max()), msg="demb")
