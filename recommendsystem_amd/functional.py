@@ -139,6 +139,30 @@ def embedding_lookup(idx, holder, weights) -> torch.Tensor:
     return _GatherFn.apply(idx, holder, *weights)
 
 
+class _HeadSum:
+    """sum_b dL/dlogit[b] of the last loss head, which its launch leaves behind for nothing (bce_of_logits): whoever
+    needs the batch sum of exactly that gradient -- the bias of the LR layer (Layers.py:104-109), the bias of a 1-wide
+    last Linear (DCN.py:31) -- takes it from here instead of summing B values in two launches.  `dz` is kept alive so
+    that no other tensor can sit at its address while the entry is valid."""
+    dz = None
+    total = None
+
+
+def batch_sum_of(g, out=None, parts=None):
+    """sum over the batch of the gradient g ([B] or [B, 1]) as a 1-element tensor (written to `out` when given).  parts:
+    a ColsumParts collector whose finish() the caller runs anyway; the result is then valid after it."""
+    hs = _HeadSum
+    if (hs.dz is not None and g.is_contiguous() and g.numel() == hs.dz.numel() and g.data_ptr() == hs.dz.data_ptr()):
+        if out is None:
+            return hs.total
+        if parts is not None:
+            parts.add(hs.total, 1, 1, 1, dest=out)
+            return out
+        out.copy_(hs.total)
+        return out
+    return ops.colsum(g.reshape(-1, 1), out=out)
+
+
 class _LRFn(torch.autograd.Function):
     """(B, 1) = sum_f w_f[idx[f, b]] + bias   (Layers.py:107-109)."""
 
@@ -179,7 +203,7 @@ class _BiasGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        return g, ops.colsum(g.view(-1, 1))
+        return g, batch_sum_of(g)
 
 
 def lr_forward(idx, holder, bias, weights1) -> torch.Tensor:
@@ -338,7 +362,7 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
         parts = colsum_parts if colsum_parts is not None else ops.ColsumParts(ops.default_workspace(dz.device))
         dW = dW_out if dW_out is not None else torch.empty_like(c.W)
         if not db_done:
-            out["db"] = ops.colsum(dz.view(-1, 1), out=db_out)
+            out["db"] = batch_sum_of(dz, out=db_out, parts=parts)
         out["dx"] = ops.head_bwd(dz.reshape(-1), c.W.reshape(-1), c.x, mul_act if mulsrc is not None else 0, parts,
                                  dW_out=dW.view(-1), dbp_out=dbp_out if mulsrc is not None else None)
         if own:
@@ -667,8 +691,11 @@ class _BCEHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, y, assume_grad):
+        total = torch.empty(1, dtype=torch.float32, device=z.device) if assume_grad is not None else None
         r = ops.bce_head([z.contiguous().view(-1)], y, want_dz=True,
-                         grad_scale=1.0 if assume_grad is None else float(assume_grad))
+                         grad_scale=1.0 if assume_grad is None else float(assume_grad), sum_dz_out=total)
+        # dL/dz is final only when the incoming gradient is known in advance; then its batch sum is on offer
+        _HeadSum.dz, _HeadSum.total = (r["dz"], total) if assume_grad is not None else (None, None)
         ctx.dz = r["dz"]
         ctx.shape = z.shape
         ctx.assumed = assume_grad is not None
