@@ -177,6 +177,14 @@ int rs_head_fwd_bwd(const float* X, int B, int K, const float* w, const float* b
 int rs_head_bwd_rows(int B);
 int rs_head_bwd(const float* dzh, const float* w, const float* X, int mul_act, int B, int K, float* dX, float* part,
                 rs_stream_t stream);
+/* The 1-wide layer over cat([X1, X2], 1) without the concatenation -- DCN's Linear(D + h_last, 1) over the cross
+ * network's output and the deep tower's (model/DCN/DCN.py:31,52): h[m] = act(X1[m,:].w[:K1] + X2[m,:].w[K1:] + b);
+ * the backward is rs_head_bwd with dX and the columns of part [rs_head_bwd_rows(B), 2*(K1+K2)] split the same way,
+ * mul_act2 = the activation whose output X2 is (0: none).  K1 + K2 <= 1024. */
+int rs_rowdot2_fwd(const float* X1, int K1, const float* X2, int K2, int M, const float* w, const float* bias, int act,
+                   float* h, rs_stream_t stream);
+int rs_head2_bwd(const float* dzh, const float* w, const float* X1, int K1, const float* X2, int K2, int mul_act2, int B,
+                 float* dX1, float* dX2, float* part, rs_stream_t stream);
 
 /* ---- K2: interactions on gathered embeddings emb[B,F,d] -------------------------------------- */
 int rs_fm_fwd(const float* emb, int B, int F, int d, float* sum_out, float* bi_out, float* fm_out, rs_stream_t stream);

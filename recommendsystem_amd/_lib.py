@@ -79,6 +79,8 @@ _SIGS = {
     "rs_head_fwd_bwd": [c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_f32p, c_f32p, c_i64p, F, c_f32p, c_f32p, c_f32p,
                         c_f32p, I, c_f32p, c_f32p, c_stream],
     "rs_head_bwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
+    "rs_rowdot2_fwd": [c_f32p, I, c_f32p, I, I, c_f32p, c_f32p, I, c_f32p, c_stream],
+    "rs_head2_bwd": [c_f32p, c_f32p, c_f32p, I, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_act_fwd": [c_f32p, c_f32p, L, I, c_f32p, c_stream],
     "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
     "rs_bn_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, I, F, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],

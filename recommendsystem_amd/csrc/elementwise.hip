@@ -78,6 +78,36 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     if (lane == 0) h[m] = rs_act(act, s + (bias ? bias[0] : 0.f), 0.f);
 }
 
+// The same for an input given as two column blocks, h[m] = act(x1[m,:].w[:K1] + x2[m,:].w[K1:] + b): a 1-wide Linear
+// over cat([x1, x2], 1) (model/DCN/DCN.py:31,52) without the concatenation.
+__global__ __launch_bounds__(256) void rowdot2_fwd_kernel(const float* __restrict__ X1, int K1, const float* __restrict__ X2,
+                                                          int K2, int M, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int act, float* __restrict__ h) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x1 = X1 + (long long)m * K1;
+    const float* x2 = X2 + (long long)m * K2;
+    float s = 0.f;
+    if (((K1 | K2) & 3) == 0) {
+        for (int k = lane * 4; k < K1; k += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(x1 + k);
+            const float4 b = *reinterpret_cast<const float4*>(w + k);
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+        for (int k = lane * 4; k < K2; k += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(x2 + k);
+            const float4 b = *reinterpret_cast<const float4*>(w + K1 + k);
+            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+        }
+    } else {
+        for (int k = lane; k < K1; k += 64) s = fmaf(x1[k], w[k], s);
+        for (int k = lane; k < K2; k += 64) s = fmaf(x2[k], w[K1 + k], s);
+    }
+    s = rs_wave_sum(s);
+    if (lane == 0) h[m] = rs_act(act, s + (bias ? bias[0] : 0.f), 0.f);
+}
+
 // dX[m,k] = dz[m] * w[k] * act'_prev(X[m,k])   (X is the previous block's output; mul_act = its activation)
 __global__ __launch_bounds__(256) void rowdot_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                             const float* __restrict__ X, int mul_act, int M, int K,
@@ -215,6 +245,46 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             float v = g * wk;
             if (mul_act) v *= rs_act_grad(mul_act, x[r], x[r], 0.f);
             if (r0 + r < B) dX[(long long)(r0 + r) * K + k] = v;
+            aw = fmaf(g, x[r], aw);
+            ab += v;
+        }
+        prow[k] = aw;
+        prow[K + k] = ab;
+    }
+}
+
+// head_bwd_kernel for an input given as two column blocks X1 [B,K1], X2 [B,K2] (rowdot2_fwd_kernel): column k < K1 of
+// the concatenation lives in X1 / dX1, the others in X2 / dX2; mul_act2 (the activation whose output X2 is) applies
+// to the second block only.  part: [grid, 2, K1 + K2].
+__global__ __launch_bounds__(256) void head2_bwd_kernel(const float* __restrict__ dzh, const float* __restrict__ w,
+                                                        const float* __restrict__ X1, int K1, const float* __restrict__ X2,
+                                                        int K2, int mul_act2, int B, float* __restrict__ dX1,
+                                                        float* __restrict__ dX2, float* __restrict__ part) {
+    __shared__ float sdz[HEAD_ROWS];
+    const int r0 = blockIdx.x * HEAD_ROWS, K = K1 + K2;
+    if (threadIdx.x < HEAD_ROWS) sdz[threadIdx.x] = r0 + threadIdx.x < B ? dzh[r0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    float* prow = part + (long long)blockIdx.x * 2 * K;
+#pragma unroll
+    for (int u = 0; u < HEAD_KPT; ++u) {
+        const int k = threadIdx.x + u * 256;
+        if (k >= K) break;
+        const bool second = k >= K1;
+        const float* X = second ? X2 : X1;
+        float* dX = second ? dX2 : dX1;
+        const int kk = second ? k - K1 : k, Kx = second ? K2 : K1;
+        const int ma = second ? mul_act2 : 0;
+        const float wk = w[k];
+        float x[HEAD_ROWS];
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) x[r] = r0 + r < B ? X[(long long)(r0 + r) * Kx + kk] : 0.f;
+        float aw = 0.f, ab = 0.f;
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) {
+            const float g = sdz[r];
+            float v = g * wk;
+            if (ma) v *= rs_act_grad(ma, x[r], x[r], 0.f);
+            if (r0 + r < B) dX[(long long)(r0 + r) * Kx + kk] = v;
             aw = fmaf(g, x[r], aw);
             ab += v;
         }
@@ -668,6 +738,32 @@ int rs_head_bwd(const float* dzh, const float* w, const float* X, int mul_act, i
     RS_CHECK_ARG(dzh && w && X && dX && part, "rs_head_bwd: null argument");
     hipLaunchKernelGGL(head_bwd_kernel, dim3(rs_cdiv(B, HEAD_ROWS)), dim3(256), 0, stream, dzh, w, X, mul_act, B, K, dX, part);
     RS_CHECK_LAUNCH("rs_head_bwd");
+    return RS_OK;
+}
+
+// The 1-wide layer over cat([X1, X2], 1) without the concatenation (DCN.py:31,52: Linear(D + h_last, 1) over the cross
+// network's output and the deep tower's): w [K1 + K2]; backward as rs_head_bwd with dX and the columns of part split
+// the same way, mul_act2 = the activation whose output X2 is (0: none).  K1 + K2 <= 1024.
+int rs_rowdot2_fwd(const float* X1, int K1, const float* X2, int K2, int M, const float* w, const float* bias, int act,
+                   float* h, hipStream_t stream) {
+    RS_CHECK_ARG(M >= 0 && K1 > 0 && K2 > 0, "rs_rowdot2_fwd: bad sizes");
+    if (M == 0) return RS_OK;
+    RS_CHECK_ARG(X1 && X2 && w && h, "rs_rowdot2_fwd: null argument");
+    RS_CHECK_ARG(((K1 | K2) & 3) != 0 || ((reinterpret_cast<uintptr_t>(X1) | reinterpret_cast<uintptr_t>(X2) |
+                                           reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                 "rs_rowdot2_fwd: operands of widths that are multiples of four must be 16-byte aligned");
+    hipLaunchKernelGGL(rowdot2_fwd_kernel, dim3(rs_cdiv(M, 4)), dim3(256), 0, stream, X1, K1, X2, K2, M, w, bias, act, h);
+    RS_CHECK_LAUNCH("rs_rowdot2_fwd");
+    return RS_OK;
+}
+
+int rs_head2_bwd(const float* dzh, const float* w, const float* X1, int K1, const float* X2, int K2, int mul_act2, int B,
+                 float* dX1, float* dX2, float* part, hipStream_t stream) {
+    RS_CHECK_ARG(B > 0 && K1 > 0 && K2 > 0 && K1 + K2 <= 256 * HEAD_KPT, "rs_head2_bwd: bad sizes (K1 + K2 <= %d)", 256 * HEAD_KPT);
+    RS_CHECK_ARG(dzh && w && X1 && X2 && dX1 && dX2 && part, "rs_head2_bwd: null argument");
+    hipLaunchKernelGGL(head2_bwd_kernel, dim3(rs_cdiv(B, HEAD_ROWS)), dim3(256), 0, stream, dzh, w, X1, K1, X2, K2, mul_act2,
+                       B, dX1, dX2, part);
+    RS_CHECK_LAUNCH("rs_head2_bwd");
     return RS_OK;
 }
 

@@ -437,6 +437,44 @@ class _MLPBlockFn(torch.autograd.Function):
                 r["dslope"], None, None, None, None, None, None)
 
 
+class _Linear1Of2Fn(torch.autograd.Function):
+    """nn.Linear(K1 + K2, 1) over cat([x1, x2], 1) (model/DCN/DCN.py:31,52) without the concatenation and without the
+    copies that split its gradient again: one dot-product launch forward, one launch backward for dx1, dx2 and the
+    partial sums of dW."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W, b):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ctx.save_for_backward(x1, x2, W)
+        ctx.pids = (id(W), id(b))
+        return ops.rowdot2_fwd(x1, x2, W.detach().reshape(-1), b.detach(), 0).view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, W = ctx.saved_tensors
+        cap = TableCapture.active
+        sW = sb = None
+        if cap is not None and cap.grad_sinks:
+            sW, sb = cap.sink(ctx.pids[0]), cap.sink(ctx.pids[1])
+        g = g.contiguous()
+        parts = ops.ColsumParts(ops.default_workspace(g.device))
+        dW = sW if sW is not None else torch.empty_like(W)
+        db = batch_sum_of(g, out=sb, parts=parts)
+        dx1, dx2 = ops.head2_bwd(g.view(-1), W.detach().reshape(-1), x1, x2, 0, parts, dW_out=dW.view(-1))
+        parts.finish()
+        return dx1, dx2, None if sW is not None else dW, None if sb is not None else db
+
+
+def linear1_of_parts(x1, x2, W, b):
+    """[B, 1] = cat([x1, x2], 1) W^T + b for a 1-wide Linear, or None when the shape is not served."""
+    if (W.shape[0] != 1 or b is None or x1.dim() != 2 or x2.dim() != 2 or not x1.is_cuda or W.shape[1] != x1.shape[1] + x2.shape[1]
+            or W.shape[1] > _ONE_WIDE_MAX_K or x1.dtype != torch.float32 or x2.dtype != torch.float32):
+        return None
+    if (x1.shape[1] | x2.shape[1]) % 4 == 0 and W.data_ptr() % 16 != 0:
+        return None
+    return _Linear1Of2Fn.apply(x1, x2, W, b)
+
+
 def mlp_block(x2d, W, b, act, norm, gamma, beta, slope, training, running_mean, running_var, eps=1e-5):
     return _MLPBlockFn.apply(x2d, W, b, gamma, beta, slope, act, norm, training, running_mean, running_var, eps)
 

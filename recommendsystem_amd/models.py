@@ -301,4 +301,6 @@ class DCN(_CTRModel):
         emb_out = self.embedding_layer(x)
         cross_output = self.crossing_network(emb_out)
         deep_output = self.deep(emb_out)
-        return self.fc(torch.cat([cross_output, deep_output], dim=1))
+        # Linear(D + h_last, 1) over the two blocks as they are (no concatenation, no split of its gradient)
+        z = Fn.linear1_of_parts(cross_output, deep_output, self.fc.weight, self.fc.bias)
+        return z if z is not None else self.fc(torch.cat([cross_output, deep_output], dim=1))

@@ -533,6 +533,38 @@ def rowdot_fwd(x: torch.Tensor, w: torch.Tensor, bias, act: int) -> torch.Tensor
     return h
 
 
+def rowdot2_fwd(x1: torch.Tensor, x2: torch.Tensor, w: torch.Tensor, bias, act: int) -> torch.Tensor:
+    """h[m] = act(cat([x1, x2], 1)[m, :] . w + bias) without the concatenation."""
+    _chk(x1, torch.float32, "x1")
+    _chk(x2, torch.float32, "x2", (x1.shape[0], x2.shape[1]))
+    M, K1, K2 = x1.shape[0], x1.shape[1], x2.shape[1]
+    _chk(w, torch.float32, "w")
+    if w.numel() != K1 + K2:
+        raise RSError("rowdot2_fwd: weight length differs from the input width")
+    h = torch.empty(M, dtype=torch.float32, device=x1.device)
+    call("rs_rowdot2_fwd", ptr(x1), K1, ptr(x2), K2, M, ptr(w), ptr(bias), int(act), ptr(h), stream())
+    return h
+
+
+def head2_bwd(dzh: torch.Tensor, w: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, mul_act2: int, parts: "ColsumParts",
+              dW_out: torch.Tensor, dbp_out=None):
+    """Backward of rowdot2_fwd: returns (dx1, dx2) and registers the partial sums of dW_out [K1 + K2] (and of dbp_out
+    [K2] = column sums of dx2, the bias gradient of the block whose output x2 is when its act' is fused through
+    mul_act2) with `parts`."""
+    M, K1, K2 = x1.shape[0], x1.shape[1], x2.shape[1]
+    K = K1 + K2
+    _chk(dzh, torch.float32, "dzh", (M,))
+    rows = _lib.lib().rs_head_bwd_rows(M)
+    part = parts.buffer(rows * 2 * K)
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    call("rs_head2_bwd", ptr(dzh), ptr(w), ptr(x1), K1, ptr(x2), K2, int(mul_act2), M, ptr(dx1), ptr(dx2), ptr(part),
+         stream())
+    parts.add(part, rows, K, 2 * K, dest=dW_out, offset=0)
+    if dbp_out is not None:
+        parts.add(part, rows, K2, 2 * K, dest=dbp_out, offset=K + K1)
+    return dx1, dx2
+
+
 def rowdot_bwd_dx(dz: torch.Tensor, w: torch.Tensor, x: torch.Tensor, mul_act: int) -> torch.Tensor:
     """dx[m, k] = dz[m] * w[k] * act'(x[m, k])."""
     M, K = x.shape
