@@ -470,8 +470,8 @@ def linear1_of_parts(x1, x2, W, b):
     if (W.shape[0] != 1 or b is None or x1.dim() != 2 or x2.dim() != 2 or not x1.is_cuda or W.shape[1] != x1.shape[1] + x2.shape[1]
             or W.shape[1] > _ONE_WIDE_MAX_K or x1.dtype != torch.float32 or x2.dtype != torch.float32):
         return None
-    if (x1.shape[1] | x2.shape[1]) % 4 == 0 and W.data_ptr() % 16 != 0:
-        return None
+    if (x1.shape[1] | x2.shape[1]) % 4 == 0 and any(t.data_ptr() % 16 != 0 or not t.is_contiguous() for t in (x1, x2, W)):
+        return None                      # the vector loads of the kernel need 16-byte aligned rows
     return _Linear1Of2Fn.apply(x1, x2, W, b)
 
 
