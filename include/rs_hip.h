@@ -107,6 +107,11 @@ int rs_colsum_finish_multi(const float* const* part, const int* rows, const int*
 size_t rs_colsum_workspace_bytes(int M, int N);
 int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, float* out, float* workspace,
                   size_t workspace_bytes, rs_stream_t stream);
+/* Stage 1 of rs_colsum_f32 alone: part [rs_colsum_partial_rows(M), N] partial column sums, to be finished together
+ * with those of other producers by one rs_colsum_finish_multi launch (the bias gradients of a backward pass that
+ * nothing reads before the gradient norm). */
+int rs_colsum_partial_rows(int M);
+int rs_colsum_partials(const float* X, int M, int N, int ld, const float* scale, float* part, rs_stream_t stream);
 /* rs_colsum_f32 without a workspace argument, for callers that cannot allocate: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The stage-1 partial sums
  * go to a device array the library owns (4 MiB on every GPU the library runs on, held until the process ends):

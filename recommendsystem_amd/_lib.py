@@ -35,6 +35,7 @@ _SIGS = {
                          I, I, c_f32p, SZ, c_f32p, F, C.c_ulonglong, C.c_uint, C.c_ulonglong, c_i64p, c_stream],
     "rs_gemm_f32_acc": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
     "rs_colsum_f32": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, SZ, c_stream],
+    "rs_colsum_partials": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_colsum_f32_noalloc": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_gemm_f32_slabs": [I, I, I, I, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
     "rs_splitk_reduce_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
@@ -136,6 +137,7 @@ _PLAIN = {
     "rs_head_bwd_rows": (I, [I]),
     "rs_head_workspace_floats": (SZ, [I, I]),
     "rs_colsum_workspace_bytes": (SZ, [I, I]),
+    "rs_colsum_partial_rows": (I, [I]),
     "rs_colsum_noalloc_max_floats": (SZ, []),
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_pnn_outer_mlp_workspace_floats": (SZ, [I, I, I, I, I, I, L]),

@@ -1045,6 +1045,20 @@ int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, floa
     return RS_OK;
 }
 
+// Stage 1 of rs_colsum_f32 alone: part [rs_colsum_partial_rows(M), N] partial column sums (64 rows of X each) for a
+// caller that finishes several such sums in one launch (rs_colsum_finish_multi).
+int rs_colsum_partial_rows(int M) { return rs_cdiv(M, CS_ROWS); }
+int rs_colsum_partials(const float* X, int M, int N, int ld, const float* scale, float* part, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && ld >= N, "rs_colsum_partials: bad sizes");
+    RS_CHECK_ARG(X && part, "rs_colsum_partials: null argument");
+    const bool vec = aligned16(X) && ld % 4 == 0 && N % 4 == 0;
+    dim3 grid(rs_cdiv(N, 256), rs_cdiv(M, CS_ROWS));
+    if (vec) hipLaunchKernelGGL(colsum_stage1_kernel<true>, grid, dim3(256), 0, stream, X, M, N, ld, scale, part);
+    else hipLaunchKernelGGL(colsum_stage1_kernel<false>, grid, dim3(256), 0, stream, X, M, N, ld, scale, part);
+    RS_CHECK_LAUNCH("rs_colsum_partials");
+    return RS_OK;
+}
+
 // ---- the entry point that allocates nothing ---------------------------------------------------
 // rs_colsum_f32 for callers that cannot provide (or allocate) a workspace: the stage-1 partial sums go to a device
 // array that belongs to the library.  Each GPU holds its own copy of the array at its own address; the address is

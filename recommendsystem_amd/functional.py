@@ -72,7 +72,7 @@ class TableCapture:
 
     active = None
 
-    def __init__(self, provider=None, grad_sinks=None, splitk=None, on_lookup=None):
+    def __init__(self, provider=None, grad_sinks=None, splitk=None, on_lookup=None, colsum=None):
         # provider: object with emb(idx, holder) -> [B, F, d] and lr_terms(idx, holder) -> [B, F] (the per-field
         # 1-dim values) that fetches rows from somewhere else than the local stacked table (row-sharded tables)
         # grad_sinks: id(parameter) -> zero-initialised gradient tensor the MLP-block backward writes into directly
@@ -82,6 +82,9 @@ class TableCapture:
         self.provider = provider
         self.grad_sinks = grad_sinks or {}
         self.splitk = splitk
+        # colsum: an ops.ColsumParts shared by the whole backward pass: bias gradients (and other column sums) whose
+        # destination is a grad sink leave their partial sums there and the trainer finishes them all in one launch
+        self.colsum = colsum
         # on_lookup(holder, idx): called before a local table is read (the trainer brings the rows up to date)
         self.on_lookup = on_lookup
         self.rng_step = None     # device int64 counter that numbers the dropout masks of this pass (the trainer's step count)
@@ -321,7 +324,7 @@ def mlp_block_fwd(x2d, W, b, act: int, norm: Optional[str], gamma=None, beta=Non
 
 
 def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_out=None, mulsrc=None, mul_act=0,
-                  defer_reduce=None, colsum_parts=None, dbp_out=None, db_done=False, dx_dropout=None):
+                  defer_reduce=None, colsum_parts=None, dbp_out=None, db_done=False, dx_dropout=None, db_parts=None):
     """Backward of one block.  Returns dict(dx, dW, db, dgamma, dbeta, dslope).
 
     dz_ready: `dh` already is dL/dz (the caller fused act' into the GEMM that produced it).
@@ -330,6 +333,8 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
     colsum_parts/dbp_out: with a fused act', the launch that produces dx also leaves the partial column sums of dx --
     the previous block's bias gradient -- with the collector (valid in dbp_out after its finish()).
     db_done: this block's bias gradient is already on its way (the block above left it with the collector).
+    db_parts: a collector the caller finishes later; a bias gradient that needs a column-sum pass of its own then only
+    leaves its partial sums there (db_out must be given and must not be read before that finish()).
     dx_dropout: the previous block's dropout key, to be multiplied into dx in the same epilogue (with mulsrc)."""
     out = {"dgamma": None, "dbeta": None, "dslope": None, "db": None}
     fus = c.act if c.act in _FUSABLE else 0
@@ -380,7 +385,7 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
         else:
             out["dW"] = dWp[:, :c.k]
         if not db_done:
-            out["db"] = ops.colsum(dz, out=db_out)
+            out["db"] = ops.colsum(dz, out=db_out, parts=db_parts if db_out is not None else None)
         out["dx"] = None
         if need_dx:
             out["dx"] = ops.gemm(dz, c.W, b_nc=True)
@@ -392,7 +397,7 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
         return out
     out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
     if not db_done:
-        out["db"] = ops.colsum(dz, out=db_out)
+        out["db"] = ops.colsum(dz, out=db_out, parts=db_parts if db_out is not None else None)
     if need_dx:
         if mulsrc is not None and colsum_parts is not None and dbp_out is not None:
             colsum_parts.expect(dbp_out)
@@ -430,7 +435,10 @@ class _MLPBlockFn(torch.autograd.Function):
             sb = cap.sink(ctx.pids[1]) if ctx.pids[1] is not None else None
             defer = cap.splitk if sW is not None else None
         ctx.c.h, = ctx.saved_tensors
-        r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0], dW_out=sW, db_out=sb, defer_reduce=defer)
+        # with both gradients going to their sinks nothing reads them before the trainer's one finishing launch
+        shared = cap.colsum if (cap is not None and sW is not None and (sb is not None or ctx.pids[1] is None)) else None
+        r = mlp_block_bwd(dh.contiguous(), ctx.c, need_dx=ctx.needs_input_grad[0], dW_out=sW, db_out=sb, defer_reduce=defer,
+                          colsum_parts=shared if ctx.c.one else None, db_parts=shared)
         ctx.c.h = None
         # gradients written into their sinks are not handed to autograd a second time
         return (r["dx"], None if sW is not None else r["dW"], None if sb is not None else r["db"], r["dgamma"], r["dbeta"],
@@ -457,11 +465,13 @@ class _Linear1Of2Fn(torch.autograd.Function):
         if cap is not None and cap.grad_sinks:
             sW, sb = cap.sink(ctx.pids[0]), cap.sink(ctx.pids[1])
         g = g.contiguous()
-        parts = ops.ColsumParts(ops.default_workspace(g.device))
+        shared = cap.colsum if (cap is not None and sW is not None and sb is not None) else None
+        parts = shared if shared is not None else ops.ColsumParts(ops.default_workspace(g.device))
         dW = sW if sW is not None else torch.empty_like(W)
         db = batch_sum_of(g, out=sb, parts=parts)
         dx1, dx2 = ops.head2_bwd(g.view(-1), W.detach().reshape(-1), x1, x2, 0, parts, dW_out=dW.view(-1))
-        parts.finish()
+        if shared is None:
+            parts.finish()
         return dx1, dx2, None if sW is not None else dW, None if sb is not None else db
 
 
@@ -637,7 +647,9 @@ class _MLPStackFn(torch.autograd.Function):
                 t = cap.sink(ctx.pids[k]) if sinks else None
                 sunk[k] = t is not None
                 dest[k] = t if t is not None else torch.empty(ctx.shapes[k], dtype=torch.float32, device=dev)
-        parts = ops.ColsumParts(ops.default_workspace(dev))
+        # every gradient of the stack goes to a sink: nothing reads them before the trainer's one finishing launch
+        shared = cap.colsum if (sinks and all(sunk[k] for k in range(5 * n) if dest[k] is not None)) else None
+        parts = shared if shared is not None else ops.ColsumParts(ops.default_workspace(dev))
         dh = dout.contiguous()
         dz_ready = db_done = masked = False
         for i in range(n - 1, -1, -1):
@@ -658,14 +670,15 @@ class _MLPStackFn(torch.autograd.Function):
                               defer_reduce=cap.splitk if (sinks and sunk[5 * i]) else None,
                               colsum_parts=parts if (fuse_prev or c.one) else None,
                               dbp_out=dest[5 * (i - 1) + 1] if fuse_prev else None, db_done=db_done,
-                              dx_dropout=prev.drop if (fuse_prev and prev_masked) else None)
+                              dx_dropout=prev.drop if (fuse_prev and prev_masked) else None, db_parts=shared)
             masked = fuse_prev and prev_masked
             grads[5 * i + 2], grads[5 * i + 3], grads[5 * i + 4] = r["dgamma"], r["dbeta"], r["dslope"]
             dh = r["dx"]
             # the previous block's bias gradient is on its way if this block's dx launch left its partial sums
             db_done = bool(r.get("dbp_left"))
             dz_ready = fuse_prev
-        parts.finish()
+        if shared is None:
+            parts.finish()
         if ctx.out_is_h:
             cs[-1].h = None
         for k in range(5 * n):

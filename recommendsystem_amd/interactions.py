@@ -105,7 +105,7 @@ class _CrossFn(torch.autograd.Function):
                 for pid in ctx.pids:
                     cap.sink(pid)
                 g_out = torch.as_strided(peek[0].view(-1), (2 * L * D,), (1,))
-                dx0, _, _ = ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b, g_out=g_out)
+                dx0, _, _ = ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b, g_out=g_out, parts=cap.colsum)
                 return (dx0, None, *([None] * (2 * L)))
         dx0, dW, dB = ops.dcn_cross_bwd(x0, S, g.contiguous(), w, b)
         grads = [dW[l].view(ctx.shapes[l]) for l in range(L)] + [dB[l].view(ctx.shapes[L + l]) for l in range(L)]
@@ -181,7 +181,7 @@ class _AFMFn(torch.autograd.Function):
                     cap.sink(pid)
                 n = sum(t.numel() for t in peek)
                 g_out = torch.as_strided(peek[0].view(-1), (n,), (1,))
-                demb = ops.afm_bwd(emb, g.contiguous().view(-1), W, bA, h, pw, g_out=g_out)[0]
+                demb = ops.afm_bwd(emb, g.contiguous().view(-1), W, bA, h, pw, g_out=g_out, parts=cap.colsum)[0]
                 return demb, None, None, None, None, None
         demb, dW, dbA, dh, dpw, dpb = ops.afm_bwd(emb, g.contiguous().view(-1), W, bA, h, pw)
         return demb, dW, dbA, dh.view(ctx.shapes[0]), dpw.view(ctx.shapes[1]), dpb

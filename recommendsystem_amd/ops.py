@@ -306,8 +306,9 @@ class ColsumParts:
 
     Usage: p = ColsumParts(ws); p.expect(dest); ops.gemm(..., colsum_part=p); ...; p.finish()."""
 
-    def __init__(self, ws: "Workspace"):
+    def __init__(self, ws: "Workspace", tag: str = ""):
         self.ws = ws
+        self.tag = tag              # tells the scratch buffers of collectors that are open at the same time apart
         self._items = []            # (part tensor, rows, n, ld, dest)
         self._dest = None
         self._k = 0
@@ -325,7 +326,7 @@ class ColsumParts:
 
     def buffer(self, numel: int) -> torch.Tensor:
         self._k += 1
-        return self.ws.get(f"colsum_part_{self._k}", numel)
+        return self.ws.get(f"colsum_part{self.tag}_{self._k}", numel)
 
     def add(self, part: torch.Tensor, rows: int, n: int, ld: int, dest: Optional[torch.Tensor] = None, offset: int = 0):
         dest = dest if dest is not None else self.take_destination()
@@ -357,13 +358,20 @@ class ColsumParts:
         return self._arrays(items[:8]) if items else None
 
 
-def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None, scale=None) -> torch.Tensor:
-    """out[n] = sum_m scale[m] * x[m, n] (scale optional)."""
+def colsum(x: torch.Tensor, out=None, ws: Optional[Workspace] = None, scale=None, parts: "ColsumParts" = None) -> torch.Tensor:
+    """out[n] = sum_m scale[m] * x[m, n] (scale optional).  parts: a ColsumParts collector whose finish() the caller
+    runs anyway -- only the partial sums are formed here and `out` is valid after that finish()."""
     _chk(x, torch.float32, "x")
     M, N = x.shape
     _chk(scale, torch.float32, "scale", (M,))
     if out is None:
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    if parts is not None and M > 0 and N > 0:
+        rows = _lib.lib().rs_colsum_partial_rows(M)
+        part = parts.buffer(rows * N)
+        call("rs_colsum_partials", ptr(x), M, N, _chk_rows(x, "x"), ptr(scale), ptr(part), stream())
+        parts.add(part, rows, N, N, dest=out)
+        return out
     ws = ws or default_workspace(x.device)
     wbytes = _lib.lib().rs_colsum_workspace_bytes(M, N)
     wbuf = ws.get("colsum", max(wbytes // 4, 1))
@@ -1145,7 +1153,7 @@ def dcn_cross_fwd(x0: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     return out, S
 
 
-def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None):
+def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None, parts: "ColsumParts" = None):
     """-> (dx0 [B,D], dW [L,D], dB [L,D]); g_out: optional [2*L*D] destination of (dW, dB) laid end to end."""
     B, D = x0.shape
     L = w.shape[0]
@@ -1155,7 +1163,7 @@ def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None):
     dx0 = torch.empty_like(x0)
     part = torch.empty((rows, 2 * L * D), dtype=torch.float32, device=x0.device)
     call("rs_dcn_cross_bwd", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx0), ptr(part), rows, stream())
-    g = colsum(part, out=g_out)
+    g = colsum(part, out=g_out, parts=parts if g_out is not None else None)     # with parts: valid after its finish()
     return dx0, g[:L * D].view(L, D), g[L * D:].view(L, D)
 
 
@@ -1197,7 +1205,7 @@ def afm_fwd(emb, W, bA, h, pw, pb) -> torch.Tensor:
     return out
 
 
-def afm_bwd(emb, dout, W, bA, h, pw, g_out=None):
+def afm_bwd(emb, dout, W, bA, h, pw, g_out=None, parts: "ColsumParts" = None):
     """-> (demb, dW [A,d], dbA [A], dh [A], dpw [d], dpb [1]); g_out: optional [A*d + 2A + d + 1] destination of the five
     parameter gradients laid end to end in that order."""
     B, Fn, d = emb.shape
@@ -1210,7 +1218,7 @@ def afm_bwd(emb, dout, W, bA, h, pw, g_out=None):
     part = torch.empty((rows, np_), dtype=torch.float32, device=emb.device)
     call("rs_afm_bwd", ptr(emb), ptr(dout), B, Fn, d, A, ptr(W), ptr(bA), ptr(h), ptr(pw), ptr(demb), ptr(part), rows,
          stream())
-    g = colsum(part, out=g_out)
+    g = colsum(part, out=g_out, parts=parts if g_out is not None else None)     # with parts: valid after its finish()
     o = A * d
     return demb, g[:o].view(A, d), g[o:o + A], g[o + A:o + 2 * A], g[o + 2 * A:o + 2 * A + d], g[o + 2 * A + d:]
 

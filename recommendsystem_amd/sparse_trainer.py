@@ -326,7 +326,8 @@ class SparseTrainer:
         direct = not m.net_regular
         sinks = {id(p): gv for p, gv in zip(self.dense, self._gviews)} if direct else None
         splitk = ops.SplitKParts(ops.default_workspace(self.device)) if direct else None
-        with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk,
+        colsum = ops.ColsumParts(ops.default_workspace(self.device), tag="_pass") if direct else None
+        with Fn.TableCapture(provider, grad_sinks=sinks, splitk=splitk, colsum=colsum,
                              on_lookup=self._on_lookup if self.exact else None) as cap:
             cap.rng_step = self.step_count          # numbers the dropout masks: fresh ones at every (replayed) step
             if hasattr(m, "logits") and m.criterion is torch.nn.functional.binary_cross_entropy:
@@ -341,6 +342,8 @@ class SparseTrainer:
             (loss if grad_scale == 1.0 else loss * grad_scale).backward()
             if splitk is not None:
                 splitk.finish()
+            if colsum is not None:
+                colsum.finish()          # every bias gradient (and other column sum) of the pass, one launch per eight
         return cap, loss
 
     def _step_impl(self, inputs, y) -> torch.Tensor:
