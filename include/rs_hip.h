@@ -97,6 +97,24 @@ int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, i
                       int splitk, float* workspace, size_t workspace_bytes, rs_stream_t stream);
 int rs_splitk_reduce_multi(const float* const* ws, float* const* C, const long long* total, const int* splitk, int count,
                            rs_stream_t stream);
+/* Up to four independent products in ONE launch (64x64 tiles, `stages` = 2 or 3 LDS ring stages): a layer's dX and dW
+ * both need only its dZ (nn.Linear's autograd backward, Layers.py:42), and nothing reads either before the next
+ * launch, so their workgroups fill the chip together.  A descriptor with splitk == 1 is an rs_gemm_f32 product
+ * (bias / act / mulsrc / colsum_part epilogue into C; colsum_part has ceil(M/64) rows); with splitk > 1 it is an
+ * rs_gemm_f32_slabs product (slabs left in its workspace, C and the epilogue fields unused).  Operands must allow
+ * 16-byte accesses.  The products must not read one another's results. */
+typedef struct rs_gemm_desc {
+    int a_mc, b_nc, M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias; int act;
+    const float* mulsrc; int ldm; int mul_act;
+    int splitk;
+    float* workspace; size_t workspace_bytes;
+    float* colsum_part;
+} rs_gemm_desc;
+int rs_gemm_f32_group(const rs_gemm_desc* descs /* host array */, int count, int stages, rs_stream_t stream);
 /* out[p][n] = sum_{r < rows[p]} part[p][r*ld[p] + n] for n < n[p], p < count <= 8, in one launch.  The five arrays
  * are HOST arrays (of device pointers / sizes). */
 int rs_colsum_finish_multi(const float* const* part, const int* rows, const int* n, const int* ld, float* const* out,

@@ -21,6 +21,21 @@ I = C.c_int
 F = C.c_float
 L = C.c_longlong
 
+
+
+class GemmDesc(C.Structure):
+    """rs_gemm_desc of include/rs_hip.h: one product of rs_gemm_f32_group."""
+    _fields_ = [("a_mc", I), ("b_nc", I), ("M", I), ("N", I), ("K", I),
+                ("A", C.c_void_p), ("lda", I),
+                ("B", C.c_void_p), ("ldb", I),
+                ("C", C.c_void_p), ("ldc", I),
+                ("bias", C.c_void_p), ("act", I),
+                ("mulsrc", C.c_void_p), ("ldm", I), ("mul_act", I),
+                ("splitk", I),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("colsum_part", C.c_void_p)]
+
+
 # name -> argtypes (every entry point returns int, except where noted below)
 SZ = C.c_size_t
 _SIGS = {
@@ -38,6 +53,7 @@ _SIGS = {
     "rs_colsum_partials": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_colsum_f32_noalloc": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_gemm_f32_slabs": [I, I, I, I, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
+    "rs_gemm_f32_group": [C.c_void_p, I, I, c_stream],
     "rs_splitk_reduce_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     "rs_colsum_finish_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     # sparse.hip

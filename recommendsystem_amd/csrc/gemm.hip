@@ -90,9 +90,16 @@ __device__ __forceinline__ float epilogue(const GemmArgs& g, float v, int m, int
 // own L2), so the linear block id is first remapped so that the blocks sharing an XCD take one contiguous chunk
 // of the tile sequence (bijective for any grid size), and the sequence itself walks the grid in groups of 8
 // tile rows: the blocks resident on an XCD at one time then share A row panels and B column panels in its L2.
-__device__ __forceinline__ void tile_coords(int& tm, int& tn) {
-    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
-    const int orig = blockIdx.y * gx + blockIdx.x;
+// Where a workgroup stands in its product: grid of gx x gy output tiles, lin = its linear id in that grid (x fastest),
+// z = its slice of a split reduction.
+struct Blk { int gx, gy, lin, z; };
+__device__ __forceinline__ Blk blk_of_launch() {
+    return Blk{(int)gridDim.x, (int)gridDim.y, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)blockIdx.z};
+}
+
+__device__ __forceinline__ void tile_coords(const Blk& bk, int& tm, int& tn) {
+    const int gx = bk.gx, gy = bk.gy, nwg = gx * gy;
+    const int orig = bk.lin;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     constexpr int GROUP_M = 8;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
     int tile_m, tile_n;
-    tile_coords(tile_m, tile_n);
+    tile_coords(blk_of_launch(), tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
@@ -401,10 +408,10 @@ __device__ __forceinline__ void frag_pin(Frag<MC, T>& f) {
 // ---- epilogues for the 16x16 result blocks (same contracts as finish_tile / finish_tile_vec) ----------
 template <int BM, int BN>
 __device__ __forceinline__ void finish16(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm0, int wn0,
-                                         int lr, int lg, int wid, float* smem) {
+                                         int lr, int lg, int wid, float* smem, int z) {
     constexpr int RB = BM / 32, CB = BN / 32;
     const bool partial = g.splitk > 1;
-    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    float* out = partial ? g.ws + (long long)z * g.M * g.N : g.C;
     const int ldo = partial ? g.N : g.ldc;
     float cs[CB];
 #pragma unroll
@@ -446,7 +453,7 @@ __device__ __forceinline__ void finish16(const GemmArgs& g, f32x4 (&acc)[BM / 32
 // smem: BM*(BN+4) + 4*BN floats, no longer read by any wave (the caller synchronises).
 template <int BM, int BN>
 __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0, int wm0,
-                                             int wn0, int lr, int lg, float* smem) {
+                                             int wn0, int lr, int lg, float* smem, int z) {
     constexpr int RB = BM / 32, CB = BN / 32;
     constexpr int LDT = BN + 4;                      // staged row stride (keeps float4 alignment, spreads banks)
     constexpr int LPR = BN / 4;                      // lanes per staged row
@@ -462,7 +469,7 @@ __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM 
     const int tid = threadIdx.x;
     const int c4 = (tid % LPR) * 4, rr = tid / LPR;
     const int n = n0 + c4;
-    float* out = partial ? g.ws + (long long)blockIdx.z * g.M * g.N : g.C;
+    float* out = partial ? g.ws + (long long)z * g.M * g.N : g.C;
     const int ldo = partial ? g.N : g.ldc;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!partial && g.bias && n < g.N) bv = *reinterpret_cast<const float4*>(g.bias + n);
@@ -512,7 +519,7 @@ __device__ __forceinline__ void finish16_vec(const GemmArgs& g, f32x4 (&acc)[BM 
 }
 
 template <int BM, int BN, bool A_MC, bool B_NC, int NST>
-__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_dma_body(const GemmArgs& g, const Blk bk, float* smem) {
     using DA = DmaOp<BM, A_MC>;
     using DB = DmaOp<BN, B_NC>;
     constexpr int DIST = NST - 1;                  // k-tiles in flight ahead of the one being multiplied
@@ -521,16 +528,15 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     constexpr int NDMA = DA::P + DB::P;
     constexpr int NRD_ = RB * DA::NREAD + CB * DB::NREAD;
     constexpr int NRD = NRD_ > 15 ? 15 : NRD_;     // LDS reads complete in order: waiting for fewer is still right
-    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int wm0 = (wid >> 1) * (BM / 2), wn0 = (wid & 1) * (BN / 2);
     int tile_m, tile_n;
-    tile_coords(tile_m, tile_n);
+    tile_coords(bk, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int kbeg = bk.z * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + 31) / 32;
 
@@ -587,6 +593,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     // prologue: DIST tiles in flight (tiles past the end read zeros, which keeps the counts uniform)
     issue_all(0, 0);
     if constexpr (DIST > 1) issue_all(1, 1);
+    if constexpr (DIST > 2) issue_all(2, 2);
 
 #ifdef RS_GEMM_EXPERIMENT
 #define RS_CYC() ((unsigned)__builtin_amdgcn_s_memtime() & 0xFFFFF)      /* shader clock; only used where no LDS read is pending */
@@ -666,6 +673,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
         body(std::true_type{}, kt, 0);
         body(std::true_type{}, kt + 1, 1);
         if constexpr (NST > 2) body(std::true_type{}, kt + 2, 2);
+        if constexpr (NST > 3) body(std::true_type{}, kt + 3, 3);
     }
     for (; kt < nk; ++kt) {
         if (kt + DIST < nfull) body(std::true_type{}, kt, kt % NST);
@@ -677,13 +685,13 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
     if ((RS_DBG(g) & 64) && g.trace) {
         __syncthreads();
         if (RS_DBG(g) & 128) {} else {
-            if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem);
-            else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem);
+            if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem, bk.z);
+            else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem, bk.z);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tr_end = RS_CYC();
         if (lane == 0) {
-            unsigned* o = g.trace + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+            unsigned* o = g.trace + (bk.lin * 4 + wid) * 8;
             o[0] = tr_start; o[1] = tr_first; o[2] = (tr_loop_end - tr_start) & 0xFFFFF; o[3] = (tr_end - tr_start) & 0xFFFFF;
             o[4] = tr_dma; o[5] = tr_bar; o[6] = tr_lds; o[7] = nk;
         }
@@ -693,8 +701,47 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
 
     if (RS_DBG(g) & 2) { if (acc[0][0][0] == 12345.678f) g.C[0] = 1.f; return; }
     __syncthreads();                                      // every wave is done reading the LDS ring
-    if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem);
-    else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem);
+    if (g.vec_epi) finish16_vec<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, smem, bk.z);
+    else finish16<BM, BN>(g, acc, m0, n0, wm0, wn0, lr, lg, wid, smem, bk.z);
+}
+
+template <int BM, int BN, bool A_MC, bool B_NC, int NST>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_dma_body<BM, BN, A_MC, B_NC, NST>(g, blk_of_launch(), smem);
+}
+
+// Several independent products in ONE launch (64x64 tiles, NST-stage ring): the workgroups of product p take the linear
+// block ids [first[p], first[p] + tiles[p] * splitk[p]), slice-major; the starts are multiples of 8, so a product's
+// tiles keep the XCD a stand-alone launch would give them.  Products that wait for the same predecessor and whose
+// results nobody reads before the next launch (a layer's dX and dW, which both need only its dZ) fill the chip
+// together instead of one after the other with a ramp and a tail each.
+constexpr int GROUP_MAX = 4;
+struct GemmGroupArgs {
+    GemmArgs g[GROUP_MAX];
+    int first[GROUP_MAX + 1];
+    int gx[GROUP_MAX], gy[GROUP_MAX];
+    int layout[GROUP_MAX];      // 0: A, B k-contiguous; 1: A k-contiguous, B n-contiguous; 2: A m-contiguous, B n-contiguous
+    int count;
+};
+
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < GROUP_MAX; ++q)
+        if (q < a.count && b >= a.first[q]) p = q;
+    const int local = b - a.first[p];
+    const int tiles = a.gx[p] * a.gy[p];
+    const int z = local / tiles;
+    if (z >= a.g[p].splitk) return;                     // padding up to the next product's start
+    const Blk bk{a.gx[p], a.gy[p], local - z * tiles, z};
+    const int lay = a.layout[p];
+    if (lay == 0) gemm_dma_body<64, 64, false, false, NST>(a.g[p], bk, smem);
+    else if (lay == 1) gemm_dma_body<64, 64, false, true, NST>(a.g[p], bk, smem);
+    else gemm_dma_body<64, 64, true, true, NST>(a.g[p], bk, smem);
 }
 
 // Sum the split-K slabs in slab order and apply the epilogue.
@@ -863,6 +910,21 @@ __global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumFinishAr
 
 }  // namespace
 
+// One product of rs_gemm_f32_group (field for field the struct of the same name in include/rs_hip.h).
+extern "C" {
+typedef struct rs_gemm_desc {
+    int a_mc, b_nc, M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias; int act;
+    const float* mulsrc; int ldm; int mul_act;
+    int splitk;
+    float* workspace; size_t workspace_bytes;
+    float* colsum_part;
+} rs_gemm_desc;
+}
+
 extern "C" {
 
 size_t rs_gemm_workspace_bytes(int M, int N, int splitk) {
@@ -987,6 +1049,78 @@ int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, i
     RS_CHECK_ARG(splitk <= rs_cdiv(K, BK), "rs_gemm_f32_slabs: splitk %d exceeds the k-tiles of K=%d", splitk, K);
     return gemm_impl(a_mc, b_nc, M, N, K, A, lda, B, ldb, workspace, N, nullptr, RS_ACT_NONE, nullptr, 0, 0, tile, splitk,
                      workspace, workspace_bytes, nullptr, 1, 0, nullptr, stream);
+}
+
+// Up to four independent products in one launch of 64x64-tile workgroups (stages = 2 or 3 ring stages for all of
+// them).  Product p is described as for rs_gemm_f32 (unsplit: bias / activation / mulsrc / colsum_part epilogue into
+// C) or as for rs_gemm_f32_slabs (splitk > 1: slabs left in its workspace, C and the epilogue fields unused).  All
+// operands must allow 16-byte accesses (the condition under which rs_gemm_f32 takes its DMA kernel).  The caller
+// orders nothing between the products: they must not read one another's results.
+int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t stream) {
+    RS_CHECK_ARG(count >= 0 && count <= GROUP_MAX, "rs_gemm_f32_group: at most %d products", GROUP_MAX);
+    RS_CHECK_ARG(stages >= 2 && stages <= 4, "rs_gemm_f32_group: 2, 3 or 4 ring stages");
+    if (count == 0) return RS_OK;
+    RS_CHECK_ARG(d, "rs_gemm_f32_group: null argument");
+    GemmGroupArgs a{};
+    int next = 0, used = 0;
+    for (int p = 0; p < count; ++p) {
+        const rs_gemm_desc& q = d[p];
+        RS_CHECK_ARG(q.M >= 0 && q.N >= 0 && q.K >= 0, "rs_gemm_f32_group: negative size");
+        if (q.M == 0 || q.N == 0) continue;
+        RS_CHECK_ARG(q.A && q.B, "rs_gemm_f32_group: null operand");
+        RS_CHECK_ARG(!(q.a_mc && !q.b_nc), "rs_gemm_f32_group: layout (A m-contiguous, B k-contiguous) is not provided");
+        RS_CHECK_ARG(q.lda >= (q.a_mc ? q.M : q.K) && q.ldb >= (q.b_nc ? q.N : q.K), "rs_gemm_f32_group: bad leading dims");
+        RS_CHECK_ARG(q.splitk >= 1 && (q.splitk == 1 || q.splitk <= rs_cdiv(q.K, BK)),
+                     "rs_gemm_f32_group: splitk %d does not fit K=%d", q.splitk, q.K);
+        const bool va = aligned16(q.A) && q.lda % 4 == 0 && (q.a_mc ? q.M % 4 == 0 : q.K % 4 == 0);
+        const bool vb = aligned16(q.B) && q.ldb % 4 == 0 && (q.b_nc ? q.N % 4 == 0 : q.K % 4 == 0);
+        RS_CHECK_ARG(va && vb, "rs_gemm_f32_group: product %d has operands that do not allow 16-byte accesses", p);
+        GemmArgs g{};
+        g.A = q.A; g.B = q.B; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb;
+        g.splitk = q.splitk;
+        g.kchunk = rs_cdiv(rs_cdiv(q.K, q.splitk), BK) * BK;
+        if (g.kchunk == 0) g.kchunk = BK;
+        if (q.splitk > 1) {
+            RS_CHECK_ARG(q.workspace && q.workspace_bytes >= rs_gemm_workspace_bytes(q.M, q.N, q.splitk),
+                         "rs_gemm_f32_group: workspace of product %d too small for splitk=%d", p, q.splitk);
+            g.C = q.workspace; g.ldc = q.N; g.ws = q.workspace; g.defer = 1;
+            g.vec_epi = (q.N % 4 == 0 && aligned16(q.workspace)) ? 1 : 0;
+        } else {
+            RS_CHECK_ARG(q.C && q.ldc >= q.N, "rs_gemm_f32_group: bad output of product %d", p);
+            RS_CHECK_ARG(!q.mulsrc || q.ldm >= q.N, "rs_gemm_f32_group: bad ldm");
+            RS_CHECK_ARG(q.act >= RS_ACT_NONE && q.act <= RS_ACT_LEAKYRELU, "rs_gemm_f32_group: activation %d not fusable", q.act);
+            g.C = q.C; g.ldc = q.ldc; g.bias = q.bias; g.act = q.act; g.mulsrc = q.mulsrc; g.ldm = q.ldm;
+            g.mul_act = q.mul_act; g.cs_part = q.colsum_part;
+            g.vec_epi = (q.N % 4 == 0 && aligned16(q.C) && q.ldc % 4 == 0 && (!q.bias || aligned16(q.bias)) &&
+                         (!q.mulsrc || (aligned16(q.mulsrc) && q.ldm % 4 == 0))) ? 1 : 0;
+        }
+        a.g[used] = g;
+        a.gx[used] = rs_cdiv(q.N, 64);
+        a.gy[used] = rs_cdiv(q.M, 64);
+        a.layout[used] = q.a_mc ? 2 : (q.b_nc ? 1 : 0);
+        a.first[used] = next;
+        const long long blocks = (long long)a.gx[used] * a.gy[used] * q.splitk;
+        RS_CHECK_ARG(next + blocks < (1LL << 30), "rs_gemm_f32_group: too many tiles");
+        next += (int)((blocks + 7) / 8 * 8);
+        ++used;
+    }
+    if (used == 0) return RS_OK;
+    a.count = used;
+    a.first[used] = next;
+    const size_t smem = (size_t)stages * (64 + 64) * 32 * sizeof(float);
+    auto kern = stages == 2 ? gemm_f32_group_kernel<2> : stages == 3 ? gemm_f32_group_kernel<3> : gemm_f32_group_kernel<4>;
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[stages - 2]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) {
+            rs_set_error("rs_gemm_f32_group: cannot raise dynamic LDS limit to %zu", smem);
+            return RS_ERR_LAUNCH;
+        }
+        attr_set[stages - 2] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(next), dim3(256), smem, stream, a);
+    RS_CHECK_LAUNCH("rs_gemm_f32_group");
+    return RS_OK;
 }
 
 // C[p][e] = sum_z ws[p][z * total[p] + e], z < splitk[p] in slab order, e < total[p], for p < count (<= 8) products in

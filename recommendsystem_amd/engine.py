@@ -26,6 +26,8 @@ Two embedding-update modes:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
@@ -142,6 +144,8 @@ class FusedTrainer:
         self._capture_error_mode = "global"
         # the base hooks run the whole step on this GPU; subclasses that put collectives between the pieces turn it off
         self._fuse_small = type(self) is FusedTrainer
+        # LDS ring stages of the grouped dW + dX launch of a block's backward (0: one launch per product)
+        self.group_gemms = ops.GROUP_STAGES
         self.last = {}
         # device-side error flags (index out of range; on several GPUs also bucket overflow of the exchange) are read
         # every check_every steps -- a host synchronisation -- and by check() before tables are read as a whole
@@ -471,6 +475,8 @@ class FusedTrainer:
 
             # weight gradients are read by nobody before the gradient norm: their split-K slabs are reduced together
             skp = ops.SplitKParts(ops.default_workspace(self.device)) if not overlap else None
+            # a block's dW and dX need only its dZ and nothing reads either before the next launch: one launch for both
+            grp = ops.GemmGroup(self.group_gemms) if (skp is not None and self.group_gemms) else None
             db_done = False              # the bias gradient of the block about to be visited is already on its way
             if head_fast:
                 _, xin, _ = cs[top]
@@ -505,7 +511,9 @@ class FusedTrainer:
                     dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
                     keep.append(dzl)
                     gW, gb = self.gviews[id(b.fc.weight)], self.gviews[id(b.fc.bias)]
-                    if db_done:
+                    if db_done and grp is not None:
+                        grp.add(dzl, c.x, a_mc=True, b_nc=True, out=gW, defer_reduce=skp)
+                    elif db_done:
                         wgrad(lambda dzl=dzl, c=c, gW=gW: ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW, defer_reduce=skp))
                     else:
                         wgrad(lambda dzl=dzl, c=c, gW=gW, gb=gb: (ops.gemm(dzl, c.x, a_mc=True, b_nc=True, out=gW,
@@ -515,9 +523,15 @@ class FusedTrainer:
                     # sums (the previous block's bias gradient) then come out of the same launch
                     if fuse_prev:
                         csp.expect(self.gviews[id(prev.fc.bias)])
-                    dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
-                                  mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,
-                                  dropout=mask_key)
+                    if grp is not None and mask_key is None:
+                        dh = grp.add(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
+                                     mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None)
+                    else:
+                        dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
+                                      mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,
+                                      dropout=mask_key)
+                    if grp is not None:
+                        grp.launch()
                     db_done = fuse_prev
                 else:
                     r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,

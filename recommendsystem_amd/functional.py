@@ -395,17 +395,29 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             out["dx"] = ops.act_bwd(out["dx"].contiguous(), mul_act, h=mulsrc)[0]
         out["dz"] = dz
         return out
-    out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
+    # dW and dx both need only dz: one launch for the two products (ops.GemmGroup), unless a dropout mask rides in dx
+    grp = ops.GemmGroup(ops.GROUP_STAGES) if (ops.GROUP_STAGES and need_dx and dx_dropout is None) else None
+    if grp is not None:
+        out["dW"] = grp.add(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
+    else:
+        out["dW"] = ops.gemm(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
     if not db_done:
         out["db"] = ops.colsum(dz, out=db_out, parts=db_parts if db_out is not None else None)
     if need_dx:
         if mulsrc is not None and colsum_parts is not None and dbp_out is not None:
             colsum_parts.expect(dbp_out)
-            out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts,
-                                 dropout=dx_dropout)
+            if grp is not None:
+                out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts)
+            else:
+                out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts,
+                                     dropout=dx_dropout)
             out["dbp_left"] = True
+        elif grp is not None:
+            out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act)
         else:
             out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, dropout=dx_dropout)
+        if grp is not None:
+            grp.launch()
     else:
         out["dx"] = None
     out["dz"] = dz

@@ -216,3 +216,61 @@ def test_gemm_column_blocks_and_running_sum(M, N, K, pad, layout):
             a, b, kw = block(A[:, k0:k1].t().contiguous()), block(Bm[k0:k1]), dict(a_mc=True, b_nc=True)
         ops.gemm(a, b, out=out, accumulate=k0 > 0, bias=bias.to(dev) if last else None, act=ACT["tanh"] if last else 0, **kw)
     _check(out, want, bound, rel=4e-6)
+
+
+@pytest.mark.parametrize("stages", [2, 3])
+def test_grouped_products_equal_single_launches(stages):
+    """rs_gemm_f32_group: a layer's dW (split, slabs reduced later), its dX with the act' factor and the bias-gradient
+    by-product, a forward product with bias + activation and a ragged unsplit dW in ONE launch give the bits of the
+    four single launches."""
+    from recommendsystem_amd import ops
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    B, n_in, n_out = 1024, 200, 136
+    dz = torch.randn(B, n_out, generator=g).to(DEV)
+    x = torch.randn(B, n_in, generator=g).to(DEV)
+    W = torch.randn(n_out, n_in, generator=g).to(DEV)
+    hprev = torch.randn(B, n_in, generator=g).to(DEV)
+    bias = torch.randn(n_out, generator=g).to(DEV)
+    xs = torch.randn(100, 36, generator=g).to(DEV)
+    dzs = torch.randn(100, 52, generator=g).to(DEV)
+
+    ws = ops.Workspace(torch.device(DEV))
+    # single launches
+    sk1 = ops.SplitKParts(ws)
+    dW1 = torch.empty(n_out, n_in, device=DEV)
+    ops.gemm(dz, x, a_mc=True, b_nc=True, out=dW1, tile=3, splitk=4, defer_reduce=sk1)
+    sk1.finish()
+    cs1 = ops.ColsumParts(ws, "one")
+    db1 = torch.zeros(n_in, device=DEV)
+    cs1.expect(db1)
+    dX1 = ops.gemm(dz, W, b_nc=True, mulsrc=hprev, mul_act=1, tile=5, splitk=1, colsum_part=cs1)
+    cs1.finish()
+    H1 = ops.gemm(x, W, bias=bias, act=2, tile=5, splitk=1)
+    dWs1 = ops.gemm(dzs, xs, a_mc=True, b_nc=True, tile=3, splitk=1)
+
+    # one launch
+    grp = ops.GemmGroup(stages)
+    sk2 = ops.SplitKParts(ws)
+    dW2 = torch.full((n_out, n_in), float("nan"), device=DEV)
+    grp.add(dz, x, a_mc=True, b_nc=True, out=dW2, splitk=4, defer_reduce=sk2)
+    cs2 = ops.ColsumParts(ws, "two")
+    db2 = torch.zeros(n_in, device=DEV)
+    cs2.expect(db2)
+    dX2 = grp.add(dz, W, b_nc=True, mulsrc=hprev, mul_act=1, splitk=1, colsum_part=cs2)
+    H2 = grp.add(x, W, bias=bias, act=2, splitk=1)
+    dWs2 = grp.add(dzs, xs, a_mc=True, b_nc=True, splitk=1)
+    assert len(grp) == 4
+    grp.launch()
+    sk2.finish()
+    cs2.finish()
+    assert torch.equal(dW2, dW1)
+    assert torch.equal(dX2, dX1)
+    assert torch.equal(db2, db1)
+    assert torch.equal(H2, H1)
+    assert torch.equal(dWs2, dWs1)
+    # an operand that does not allow 16-byte accesses goes through a launch of its own
+    a_odd = torch.randn(64, 33, generator=g).to(DEV)
+    b_odd = torch.randn(48, 33, generator=g).to(DEV)
+    o = grp.add(a_odd, b_odd)
+    assert len(grp) == 0 and torch.equal(o, ops.gemm(a_odd, b_odd))
