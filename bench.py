@@ -331,8 +331,8 @@ def main():
             ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
             gemm_flop += a["work"] * a["n"]
             gemm_us += a["total_us"]
-            # the three kernel instantiations a profiler lists: NT = forward <false,false>, NN = dX <false,true>,
-            # TN = dW <true,true> (+ its split-K reduce launch)
+            # the kernels a profiler lists: NT = forward <false,false>, NN = dX <false,true> and TN = dW <true,true>
+            # where they are launched alone, GRP = gemm_f32_group_kernel (a block's dW slabs and its dX in one launch)
             lay = by_layout.setdefault(shape.split()[0], {"launches": 0, "total_us": 0.0})
             lay["launches"] += a["n"]
             lay["total_us"] += a["total_us"]
@@ -359,17 +359,18 @@ def main():
         if not (os.path.exists(tp) and default_cfg):
             return None
         try:
-            ks = [v for k, v in json.load(open(tp))["kernels"].items() if k.startswith(prefix)]
+            ks = [v for k, v in json.load(open(tp))["kernels"].items() if k.startswith(prefix)]     # prefix: str or tuple
             n = sum(v["launches"] for v in ks)
             return sum(v["launches"] * (v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) for v in ks) / n if n else None
         except Exception:
             return None
-    traffic = pmc_traffic("gemm_f32_dma_kernel")
+    traffic = pmc_traffic(("gemm_f32_dma_kernel", "gemm_f32_group_kernel"))
     gather_traffic = pmc_traffic("gather_fused_kernel")
     roofline = None
     if gemm_us > 0:
         ach = gemm_flop / gemm_us / 1e6
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_dma_kernel (v_mfma_f32_16x16x4_f32), all MLP GEMM launches of a step",
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_dma_kernel / gemm_f32_group_kernel (v_mfma_f32_16x16x4_f32): every MLP GEMM "
+                                               "launch of a step (NT = forward; GRP = a block's dW + dX in one launch)",
                     "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "algorithmic_flop_per_step": gemm_flop / args.steps, "us_per_step": round(gemm_us / args.steps, 1),

@@ -97,11 +97,14 @@ __device__ __forceinline__ Blk blk_of_launch() {
     return Blk{(int)gridDim.x, (int)gridDim.y, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)blockIdx.z};
 }
 
-__device__ __forceinline__ void tile_coords(const Blk& bk, int& tm, int& tn) {
-    const int gx = bk.gx, gy = bk.gy, nwg = gx * gy;
-    const int orig = bk.lin;
+// Position of linear block id `orig` (of nwg ids dealt round-robin over the 8 XCDs) in a sequence in which every XCD
+// owns one contiguous chunk (bijective for any nwg).
+__device__ __forceinline__ int xcd_chunked(int orig, int nwg) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+// Tile t of the walk over a gx x gy tile grid in groups of 8 tile rows, column by column inside a group.
+__device__ __forceinline__ void grouped_walk(int t, int gx, int gy, int& tm, int& tn) {
     constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * gx;
     const int group = t / per_group, first_m = group * GROUP_M;
@@ -109,6 +112,11 @@ __device__ __forceinline__ void tile_coords(const Blk& bk, int& tm, int& tn) {
     const int rem = t - group * per_group;
     tm = first_m + rem % gsz;
     tn = rem / gsz;
+}
+// bk.lin < 0: bk.gx already holds the tile column and bk.gy the tile row (the caller did the mapping).
+__device__ __forceinline__ void tile_coords(const Blk& bk, int& tm, int& tn) {
+    if (bk.lin < 0) { tn = bk.gx; tm = bk.gy; return; }
+    grouped_walk(xcd_chunked(bk.lin, bk.gx * bk.gy), bk.gx, bk.gy, tm, tn);
 }
 
 // ---- tile epilogue shared by both kernels ----------------------------------------------------------
@@ -734,10 +742,16 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs a) {
     for (int q = 1; q < GROUP_MAX; ++q)
         if (q < a.count && b >= a.first[q]) p = q;
     const int local = b - a.first[p];
-    const int tiles = a.gx[p] * a.gy[p];
-    const int z = local / tiles;
-    if (z >= a.g[p].splitk) return;                     // padding up to the next product's start
-    const Blk bk{a.gx[p], a.gy[p], local - z * tiles, z};
+    const int tiles = a.gx[p] * a.gy[p], nwg = tiles * a.g[p].splitk;
+    if (local >= nwg) return;                           // padding up to the next product's start
+    // An XCD takes one contiguous chunk of the (slice, tile) sequence: with the reduction split, the workgroups that
+    // share an L2 then work inside one or two slices and read each operand panel of their slice once, instead of every
+    // slice being spread over all eight L2s.
+    const int t = xcd_chunked(local, nwg);
+    const int z = t / tiles;
+    int tm, tn;
+    grouped_walk(t - z * tiles, a.gx[p], a.gy[p], tm, tn);
+    const Blk bk{tn, tm, -1, z};
     const int lay = a.layout[p];
     if (lay == 0) gemm_dma_body<64, 64, false, false, NST>(a.g[p], bk, smem);
     else if (lay == 1) gemm_dma_body<64, 64, false, true, NST>(a.g[p], bk, smem);

@@ -36,7 +36,18 @@ def _gather_key(args):
     return ("rs_gather_lr_fm_fwd", f"B={B} F={F} d={d}"), float(byts), "byte"
 
 
-KEYERS = {"rs_gemm_f32": _gemm_key, "rs_gather_lr_fm_fwd": _gather_key}
+def _group_key(args):
+    # (descriptor array, count, stages, stream): the products of one grouped launch and their summed work
+    descs, count = args[0], args[1]
+    parts, work = [], 0.0
+    for i in range(count):
+        d = descs[i]
+        parts.append(f"{'T' if d.a_mc else 'N'}{'N' if d.b_nc else 'T'}:M={d.M},N={d.N},K={d.K}")
+        work += 2.0 * d.M * d.N * d.K
+    return ("rs_gemm_f32_group", "GRP " + " ".join(parts)), work, "flop"
+
+
+KEYERS = {"rs_gemm_f32": _gemm_key, "rs_gemm_f32_group": _group_key, "rs_gather_lr_fm_fwd": _gather_key}
 
 
 class KernelTimer:
