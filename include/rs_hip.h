@@ -331,11 +331,13 @@ int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int
                        const int64_t* row_offset, int* plan, rs_stream_t stream);
 /* rs_sparse_bwd_sort of a columnar batch idx [F, B] (sub_off[f] = f*B, sub_cnt[f] = B, pay_base[f] = f, stride F)
  * and rs_gather_lr_fm_fwd of the same batch in ONE launch: both need only the batch, and the sort occupies just F
- * workgroups, so the gather runs beside it (Layers.py:137-160 forward + the index bookkeeping of its backward). */
+ * workgroups, so the gather runs beside it (Layers.py:137-160 forward + the index bookkeeping of its backward).
+ * resume_passes > 0: the sort was begun by rs_sort_catchup(..., split_passes = resume_passes) on the same plan and
+ * batch; this launch runs its remaining radix passes and writes the plan. */
 int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
                    const int64_t* vocab, const int64_t* row_offset, int* plan, const float* table, const float* table1,
                    const float* bias, float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B,
-                   int F, int d, int* err_flag, rs_stream_t stream);
+                   int F, int d, int* err_flag, int resume_passes, rs_stream_t stream);
 /* Row gradient of every touched row = sum over its entries r (sample b = r / Fdiv) of
  *   gout[r,:] + dfm[b]*(S[b,:] - emb[r,:])      and, for the 1-dim tables, g1src[r] + dlr[b]
  * (each term optional).  Also writes rs_sparse_bwd_num_partials(F,cap,d) partial sums of ||g||^2. */
@@ -425,11 +427,15 @@ int rs_adam_catchup_lists(const int64_t* keys, const int* sub_off, const int* su
                           int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
                           int mark_ahead, const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
 /* rs_sparse_bwd_sort of a columnar batch and rs_adam_catchup (mark_ahead = 0) of the same batch in one launch: the sort
- * keeps one workgroup per field busy, the replay runs on the workgroups behind them. */
+ * keeps one workgroup per field busy, the replay runs on the workgroups behind them.
+ * split_passes > 0 (B <= rs_sort_split_max_entries()): only the first split_passes radix passes of the sort run here
+ * and the plan is not written yet; rs_sort_gather(..., resume_passes = split_passes) finishes it beside the gather, so
+ * that neither of the two launches in front of the first GEMM is as long as the whole sort. */
+int rs_sort_split_max_entries(void);
 int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
                     const int64_t* vocab, const int64_t* row_offset, int* plan, int B, int F, int d, float* table, float* m,
                     float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
-                    const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
+                    const float* hyper, const float* bctab, int tab_n, int kmax, int split_passes, rs_stream_t stream);
 int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, int d, int opt, const long long* step,
                   const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
 

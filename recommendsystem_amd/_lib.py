@@ -60,7 +60,7 @@ _SIGS = {
     "rs_sparse_bwd_sort": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
     "rs_sparse_bwd_merge_lists": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, I, I, I, I, c_i64p, c_i64p, c_i32p, c_stream],
     "rs_sort_gather": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                       c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
+                       c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, I, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
                              c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_sparse_bwd_reduce_sumsq": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
@@ -84,7 +84,7 @@ _SIGS = {
     "rs_adam_catchup_lists": [c_i64p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p,
                               c_f32p, c_i32p, I, c_i64p, I, c_f32p, c_f32p, I, I, c_stream],
     "rs_sort_catchup": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p,
-                        c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
+                        c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p, c_f32p, c_f32p, I, I, I, c_stream],
     "rs_adam_flush": [c_f32p, c_f32p, c_f32p, c_i32p, L, I, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
     # elementwise.hip
     "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F,
@@ -161,6 +161,7 @@ _PLAIN = {
     "rs_pnn_inner_cat_ok": (I, [I, I]),
     "rs_sort_max_entries": (I, []),
     "rs_merge_max_entries": (I, []),
+    "rs_sort_split_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),
     "rs_act_bwd_num_partials": (I, [L]),

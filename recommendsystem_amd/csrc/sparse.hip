@@ -44,6 +44,11 @@ struct SortArgs {
     int* seg_row;             // [F, cap]   stacked-table row of each segment
     int* seg_first_chunk;     // [F, cap+1] first chunk of each segment (+ sentinel)
     int* counts;              // [F, 4]     n, n_chunk, n_seg, n_padding
+    // A one-workgroup sort may be cut in two launches (each beside other work that needs only the batch):
+    // phase 1 loads the lists, runs the first split_passes radix passes and leaves the items in spill [F, cap];
+    // phase 2 picks them up, runs the remaining passes and writes the plan.  phase 0: the whole sort.
+    int phase, split_passes;
+    unsigned long long* spill;
 };
 
 // Exclusive scan of one int per thread over the 1024-thread workgroup; *total gets the sum.
@@ -74,9 +79,13 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int
 // contiguous run of elements: one ballot per digit bit gives, for every digit value, the run's count
 // (lanes 0..NB-1 each build the mask of "their" value) and every lane's rank inside the run; an exclusive
 // scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that NB * runs = 1024.
+template <int ITEMS> constexpr int radix_digit_bits() {
+    return ITEMS == 1 ? 6 : (ITEMS == 2 ? 5 : (ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2)));
+}
+// passes over the key bits [bit_lo, nbits), bit_lo a multiple of the digit width
 template <int ITEMS>
-__device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scratch, int nbits) {
-    constexpr int DB = ITEMS == 1 ? 6 : (ITEMS == 2 ? 5 : (ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2)));
+__device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scratch, int nbits, int bit_lo = 0) {
+    constexpr int DB = radix_digit_bits<ITEMS>();
     constexpr int NB = 1 << DB;
     constexpr int G = 16 * ITEMS;                 // runs of 64 elements
     static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
@@ -84,7 +93,7 @@ __device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scrat
     int* cnt = scratch + 32;                      // [NB][G]
     const int lane = t & 63, w = t >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int bit = 0; bit < nbits; bit += DB) {
+    for (int bit = bit_lo; bit < nbits; bit += DB) {
         const int sh = 32 + bit;
         unsigned long long x[ITEMS], mk[ITEMS];
         int dg[ITEMS];
@@ -212,24 +221,37 @@ __device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
     int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32] + [1024]
     const int t = threadIdx.x;
     constexpr int CAPB = SORT_THREADS * ITEMS;
+    const int nbits = key_bits(a.vocab[f]);
+    const int split_bit = radix_digit_bits<ITEMS>() * a.split_passes;
+    unsigned long long* spill = a.spill + (long long)f * a.cap;
 
-    // ---- load the field's sub-lists into LDS in list order (position = order of arrival) ----
     int n = 0;
-    for (int s = 0; s < a.nsrc; ++s) {
-        const int cnt = a.sub_cnt[s * a.F + f];
-        const int off = a.sub_off[s * a.F + f];
-        const int pb = a.pay_base[s * a.F + f];
-        const long long V = a.vocab[f];
-        for (int j = t; j < cnt; j += SORT_THREADS) {
-            long long k = a.keys[off + j];
-            if (k < 0 || k >= V) k = 0;    // out-of-range was flagged by the forward; treat as padding
-            buf[n + j] = ((unsigned long long)(unsigned)k << 32) | (unsigned)(pb + j * a.pay_stride);
+    if (a.phase != 2) {
+        // ---- load the field's sub-lists into LDS in list order (position = order of arrival) ----
+        for (int s = 0; s < a.nsrc; ++s) {
+            const int cnt = a.sub_cnt[s * a.F + f];
+            const int off = a.sub_off[s * a.F + f];
+            const int pb = a.pay_base[s * a.F + f];
+            const long long V = a.vocab[f];
+            for (int j = t; j < cnt; j += SORT_THREADS) {
+                long long k = a.keys[off + j];
+                if (k < 0 || k >= V) k = 0;    // out-of-range was flagged by the forward; treat as padding
+                buf[n + j] = ((unsigned long long)(unsigned)k << 32) | (unsigned)(pb + j * a.pay_stride);
+            }
+            n += cnt;
         }
-        n += cnt;
+    } else {
+        for (int s = 0; s < a.nsrc; ++s) n += a.sub_cnt[s * a.F + f];
+        for (int j = t; j < n; j += SORT_THREADS) buf[j] = spill[j];
     }
     for (int j = n + t; j < CAPB; j += SORT_THREADS) buf[j] = ~0ull;   // sentinels sort last
     __syncthreads();
-    radix_passes<ITEMS>(buf, scratch, key_bits(a.vocab[f]));
+    if (a.phase == 1) {
+        radix_passes<ITEMS>(buf, scratch, min(nbits, split_bit));
+        for (int j = t; j < n; j += SORT_THREADS) spill[j] = buf[j];    // the sentinels stay behind the n items
+        return;
+    }
+    radix_passes<ITEMS>(buf, scratch, nbits, a.phase == 2 ? split_bit : 0);
     segment_tail<ITEMS>(a, f, buf, scratch, n);
 }
 
@@ -1024,7 +1046,7 @@ int rs_sparse_bwd_sort(const int64_t* keys, const int* sub_off, const int* sub_c
     RS_CHECK_ARG(max_entries <= SORT_THREADS * 16,
                  "rs_sparse_bwd_sort: %d entries per field exceed the in-LDS sort limit %d", max_entries,
                  SORT_THREADS * 16);
-    SortArgs a;
+    SortArgs a{};
     a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
     a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
     const PlanView pv = carve_plan(plan, F, cap);
@@ -1083,7 +1105,7 @@ int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int
     RS_CHECK_ARG(max_entries > 0 && max_entries <= cap, "rs_sparse_bwd_merge_lists: max_entries %d exceeds plan capacity %d", max_entries, cap);
     RS_CHECK_ARG(max_entries <= MERGE_MAX_ENTRIES, "rs_sparse_bwd_merge_lists: %d entries per field exceed the limit %d",
                  max_entries, MERGE_MAX_ENTRIES);
-    SortArgs a;
+    SortArgs a{};
     a.keys = keys; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = pay_stride;
     a.nsrc = nsrc; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
     const PlanView pv = carve_plan(plan, F, cap);
@@ -1114,11 +1136,12 @@ int rs_sparse_bwd_merge_lists(const int64_t* keys, const int* sub_off, const int
 }
 
 // rs_sparse_bwd_sort of a columnar batch idx [F, B] (entry (f, b) names gradient row b*F + f) and
-// rs_gather_lr_fm_fwd of the same batch in one launch.
+// rs_gather_lr_fm_fwd of the same batch in one launch.  resume_passes > 0: the sort was begun by rs_sort_catchup with
+// split_passes = resume_passes on the same plan and batch; this launch runs its remaining passes and writes the plan.
 int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
                    const int64_t* vocab, const int64_t* row_offset, int* plan, const float* table, const float* table1,
                    const float* bias, float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B,
-                   int F, int d, int* err_flag, hipStream_t stream) {
+                   int F, int d, int* err_flag, int resume_passes, hipStream_t stream) {
     RS_CHECK_ARG(idx && sub_off && sub_cnt && pay_base && vocab && row_offset && plan, "rs_sort_gather: null argument");
     RS_CHECK_ARG(B > 0 && F > 0 && d > 0 && L > 0 && cap >= B, "rs_sort_gather: bad sizes");
     RS_CHECK_ARG(B <= SORT_THREADS * 16, "rs_sort_gather: %d entries per field exceed the in-LDS sort limit %d", B,
@@ -1126,7 +1149,7 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
     RS_CHECK_ARG(table || table1, "rs_sort_gather: both tables are null");
     RS_CHECK_ARG(table || !(emb_out || sum_out || bi_out || fm_out), "rs_sort_gather: embedding outputs requested without a table");
     RS_CHECK_ARG(table1 || !lr_out, "rs_sort_gather: lr_out requested without table1");
-    SortArgs a;
+    SortArgs a{};
     a.keys = idx; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = F;
     a.nsrc = 1; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
     const PlanView pv = carve_plan(plan, F, cap);
@@ -1140,6 +1163,9 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
     const int spw = 64 / (ga.G * ga.C);
     const int gblocks = rs_cdiv(rs_cdiv(B, spw), SORT_THREADS / 64);
     TwoLevelShape sh;
+    RS_CHECK_ARG(resume_passes >= 0 && (resume_passes == 0 || !two_level_shape(B, 1, &sh)),
+                 "rs_sort_gather: a sort of %d entries per field is not cut in two launches", B);
+    if (resume_passes > 0) { a.phase = 2; a.split_passes = resume_passes; a.spill = plan_tiles(plan, F, cap); }
     if (two_level_shape(B, 1, &sh)) {
         unsigned long long* tiles64 = plan_tiles(plan, F, cap);
         const size_t tsm = sort_lds(sh.it);
@@ -1185,10 +1211,14 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
 }
 
 // rs_sparse_bwd_sort of a columnar batch with rs_adam_catchup (mark_ahead = 0) of the same batch in one launch.
+// split_passes > 0 (B <= rs_sort_split_max_entries()): only the first split_passes radix passes run here and the plan
+// is NOT written; rs_sort_gather(..., resume_passes = split_passes) on the same plan and batch finishes the sort beside
+// the gather, so that neither launch is as long as the whole sort.
+int rs_sort_split_max_entries(void) { return TWO_LEVEL_ABOVE; }
 int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, const int* pay_base, int cap, int L,
                     const int64_t* vocab, const int64_t* row_offset, int* plan, int B, int F, int d, float* table, float* m,
                     float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt, const long long* step,
-                    const float* hyper, const float* bctab, int tab_n, int kmax, hipStream_t stream) {
+                    const float* hyper, const float* bctab, int tab_n, int kmax, int split_passes, hipStream_t stream) {
     RS_CHECK_ARG(idx && sub_off && sub_cnt && pay_base && vocab && row_offset && plan && step && hyper,
                  "rs_sort_catchup: null argument");
     RS_CHECK_ARG(B > 0 && F > 0 && L > 0 && cap >= B, "rs_sort_catchup: bad sizes");
@@ -1196,7 +1226,7 @@ int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, 
                  SORT_THREADS * 16);
     RS_CHECK_ARG(opt == RS_OPT_ADAM || opt == RS_OPT_ADAMW, "rs_sort_catchup: optimizer %d has nothing to replay", opt);
     RS_CHECK_ARG(kmax >= 0 && tab_n >= 0 && (tab_n == 0 || bctab), "rs_sort_catchup: bad replay table");
-    SortArgs a;
+    SortArgs a{};
     a.keys = idx; a.sub_off = sub_off; a.sub_cnt = sub_cnt; a.pay_base = pay_base; a.pay_stride = F;
     a.nsrc = 1; a.F = F; a.cap = cap; a.L = L; a.vocab = vocab; a.row_offset = row_offset;
     const PlanView pv = carve_plan(plan, F, cap);
@@ -1210,6 +1240,9 @@ int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, 
     const int per_table = rs_cdiv((long long)B * F, SORT_THREADS);
     const int cblocks = per_table * nt;
     TwoLevelShape sh;
+    RS_CHECK_ARG(split_passes >= 0 && (split_passes == 0 || !two_level_shape(B, 1, &sh)),
+                 "rs_sort_catchup: a sort of %d entries per field is not cut in two launches", B);
+    if (split_passes > 0) { a.phase = 1; a.split_passes = split_passes; a.spill = plan_tiles(plan, F, cap); }
     if (two_level_shape(B, 1, &sh)) {
         unsigned long long* tiles64 = plan_tiles(plan, F, cap);
         const size_t tsm = sort_lds(sh.it);

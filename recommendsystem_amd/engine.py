@@ -279,8 +279,10 @@ class FusedTrainer:
         parts = []
         if self.exact and sort_plan is not None and mark_ahead == 0:
             # the replay of skipped Adam steps must precede the lookup: it shares the sort's launch, the gather follows
-            sort_plan.sort_and_catchup(idx, *self._row_states())
-            r = self._embed_forward(idx)
+            # (the sort is cut in two where it can be: its first passes here, the rest beside the gather)
+            sp = sort_plan.split_passes_for(B)
+            sort_plan.sort_and_catchup(idx, *self._row_states(), split_passes=sp)
+            r = self._embed_forward(idx) if sp == 0 else self._embed_forward_sorting(idx, sort_plan, resume_passes=sp)
         else:
             self._embed_catch_up(idx, mark_ahead)
             r = self._embed_forward(idx) if sort_plan is None else self._embed_forward_sorting(idx, sort_plan)
@@ -339,13 +341,13 @@ class FusedTrainer:
         return ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
                                     want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
 
-    def _embed_forward_sorting(self, idx, plan):
-        """_embed_forward plus the index sort of the sparse backward in the same launch."""
+    def _embed_forward_sorting(self, idx, plan, resume_passes: int = 0):
+        """_embed_forward plus the index sort of the sparse backward (or its remaining passes) in the same launch."""
         table = self.tab.stacked if self.has_emb else None
         table1 = self.tab1.stacked if self.has_lr else None
         bias = self.lrm.bias.data if self.has_lr else None
         return plan.sort_and_gather(idx, table, table1, bias, want_emb=self.has_emb, want_sum=self.has_fm,
-                                    want_lr=self.has_lr, want_fm=self.has_fm)
+                                    want_lr=self.has_lr, want_fm=self.has_fm, resume_passes=resume_passes)
 
     def _grad_scale(self) -> float:
         return 1.0

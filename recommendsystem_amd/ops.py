@@ -267,6 +267,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
 GROUP_STAGES = int(os.environ.get("RS_GROUP_GEMMS", "3"))
 
 
+# Radix passes of the one-workgroup index sort that run in the catch-up's launch when the sort is cut in two (the rest
+# runs in the gather's launch); 0 = the whole sort beside the catch-up.  Measured at B=4096, 39 fields (rocprofv3): whole
+# sort beside the catch-up 27.7 us + gather 9.2 us; 3 passes 19.2 + 17.1; every pass of the 20-bit fields first and only
+# the segmentation beside the gather 24.2 + 11.2 -- a sort launch has about 9 us of fixed cost, so the cut buys 1-2 us.
+SORT_SPLIT_PASSES = int(os.environ.get("RS_SORT_SPLIT", "4"))
+
+
 class GemmGroup:
     """Products that may run in one launch (rs_gemm_f32_group): they wait for the same predecessor and nobody reads
     their results before the launch after them -- a layer's dX and dW.  add() takes the arguments of gemm() (64x64
@@ -731,8 +738,9 @@ class SparsePlan:
              self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan), stream())
 
     def sort_and_gather(self, idx: torch.Tensor, table, table1, bias, want_emb=True, want_sum=False, want_lr=False,
-                        want_fm=False):
-        """sort_columnar(idx) and gather_lr_fm_fwd(idx, ...) in one launch; returns the gather's dict."""
+                        want_fm=False, resume_passes: int = 0):
+        """sort_columnar(idx) and gather_lr_fm_fwd(idx, ...) in one launch; returns the gather's dict.
+        resume_passes > 0: the sort was begun by sort_and_catchup(..., split_passes=resume_passes) and is finished here."""
         Fn, B = idx.shape
         _chk(idx, torch.int64, "idx", (self.F, B))
         if B > self.cap:
@@ -761,12 +769,19 @@ class SparsePlan:
         call("rs_sort_gather", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK, ptr(layout.vocab_t),
              ptr(layout.row_offset_t), ptr(self.plan), ptr(table), ptr(table1), ptr(bias), ptr(out.get("emb")),
              ptr(out.get("sum")), ptr(None), ptr(out.get("lr")), ptr(out.get("fm")), B, Fn, d, ptr(layout.err_flag),
-             stream())
+             int(resume_passes), stream())
         return out
 
-    def sort_and_catchup(self, idx: torch.Tensor, main, one):
+    def split_passes_for(self, B: int) -> int:
+        """Radix passes of the index sort that run beside the Adam catch-up when the rest runs beside the gather
+        (0: the sort is not cut in two launches for this batch size)."""
+        return SORT_SPLIT_PASSES if B <= _lib.lib().rs_sort_split_max_entries() else 0
+
+    def sort_and_catchup(self, idx: torch.Tensor, main, one, split_passes: int = 0):
         """sort_columnar(idx) and adam_catchup(idx, layout, main, one, mark_ahead=0) in one launch (main / one: the
-        RowAdam states of the [R, d] and the 1-dim table looked up with idx; the update that follows stamps the rows)."""
+        RowAdam states of the [R, d] and the 1-dim table looked up with idx; the update that follows stamps the rows).
+        split_passes > 0: only that many radix passes of the sort run here; sort_and_gather(..., resume_passes=
+        split_passes) must follow and writes the plan."""
         Fn, B = idx.shape
         _chk(idx, torch.int64, "idx", (self.F, B))
         if B > self.cap:
@@ -782,7 +797,7 @@ class SparsePlan:
         call("rs_sort_catchup", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK, ptr(self.layout.vocab_t),
              ptr(self.layout.row_offset_t), ptr(self.plan), B, Fn, main.d if main else 1, g(main, "w"), g(main, "m"),
              g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt],
-             ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, stream())
+             ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, int(split_passes), stream())
 
     def sort_lists(self, keys, sub_off, sub_cnt, pay_base, nsrc: int, max_entries: int):
         """General form: per field, `nsrc` packed sub-lists of keys; gradient rows are packed likewise."""

@@ -139,6 +139,40 @@ def test_two_level_sort_writes_the_same_plan(B):
         assert torch.equal(q.plan[:off4], one4.plan[:off4])
 
 
+@pytest.mark.parametrize("B", [1, 700, 1024, 1500, 3000, 4096])
+@pytest.mark.parametrize("passes", [1, 2, 3, 6, 9])
+def test_sort_cut_in_two_launches_writes_the_same_plan(B, passes):
+    """The one-workgroup sort begun beside the Adam catch-up (first `passes` radix passes, items parked in the plan's
+    scratch) and finished beside the gather must write the plan of the uncut sort bit for bit -- for fields whose keys
+    need fewer passes than the first launch runs, and for fields that need more than two launches' worth -- and the
+    gather beside it must return the rows."""
+    from recommendsystem_amd import _lib, ops
+    vocabs = [3, 40, 5000, 1 << 20]
+    idx, g = _case(B, vocabs, seed=B + passes)
+    if B > 8:
+        idx[1, : B // 2] = 7
+        idx[2, ::3] = 0
+    dev = "cuda:0"
+    assert B <= _lib.lib().rs_sort_split_max_entries()
+    layout = ops.FieldLayout(vocabs, dev)
+    cap = B + 3
+    F = len(vocabs)
+    ref = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    ref.sort_columnar(idx.to(dev))
+    end = F * (6 * cap + 6)
+    w = torch.randn(layout.total_rows, 16, device=dev)
+    hyper, step = ops.make_hyper(dev, 1e-3), torch.zeros(1, dtype=torch.int64, device=dev)
+    rs = ops.RowAdam(w, torch.zeros_like(w), torch.zeros_like(w), "Adam", hyper, step)
+    p = ops.SparsePlan(layout, cap=cap, d=16, with_lr=False)
+    rows = (idx + torch.tensor(layout.row_offsets)[:, None]).t().to(dev)
+    for _ in range(2):
+        p.plan[:end].zero_()
+        p.sort_and_catchup(idx.to(dev), rs, None, split_passes=passes)
+        out = p.sort_and_gather(idx.to(dev), w, None, torch.zeros(1, device=dev), resume_passes=passes)
+        assert torch.equal(p.plan[:end], ref.plan[:end])
+        assert torch.equal(out["emb"], w[rows])
+
+
 def test_merge_reports_lists_longer_than_it_was_sized_for():
     """merge_lists told max_entries = 40 while a field's lists hold 60 keys: the field gets an empty plan (no stale
     segments) and SparsePlan.check() raises."""
