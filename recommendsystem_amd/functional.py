@@ -378,7 +378,17 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
         return out
     if c.x.shape[1] != c.k:
         # padded input width (mlp_block_fwd): the pad columns of dW and dx are zero and are cut off again
-        dWp = ops.gemm(dz, c.x, a_mc=True, b_nc=True)
+        dxp = None
+        if ops.GROUP_STAGES and need_dx:
+            # both products need only dz: one launch, the padded dW's slabs reduced right after it
+            grp = ops.GemmGroup(ops.GROUP_STAGES)
+            skp = ops.SplitKParts(ops.default_workspace(dz.device), tag="pad")
+            dWp = grp.add(dz, c.x, a_mc=True, b_nc=True, defer_reduce=skp)
+            dxp = grp.add(dz, c.W, b_nc=True)
+            grp.launch()
+            skp.finish()
+        else:
+            dWp = ops.gemm(dz, c.x, a_mc=True, b_nc=True)
         if dW_out is not None:
             dW_out.copy_(dWp[:, :c.k])
             out["dW"] = dW_out
@@ -388,7 +398,7 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             out["db"] = ops.colsum(dz, out=db_out, parts=db_parts if db_out is not None else None)
         out["dx"] = None
         if need_dx:
-            out["dx"] = ops.gemm(dz, c.W, b_nc=True)
+            out["dx"] = dxp if dxp is not None else ops.gemm(dz, c.W, b_nc=True)
             if not c.pre:
                 out["dx"] = out["dx"][:, :c.k]
         if need_dx and mulsrc is not None:

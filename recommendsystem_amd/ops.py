@@ -356,12 +356,13 @@ class SplitKParts:
     Usage: p = SplitKParts(ws); ops.gemm(..., out=dW, defer_reduce=p); ...; p.finish().  A product whose plan does
     not split is computed directly."""
 
-    def __init__(self, ws: "Workspace"):
+    def __init__(self, ws: "Workspace", tag: str = ""):
         self.ws = ws
+        self.tag = tag              # keeps the slab buffers of two collectors that share a workspace apart
         self._items = []            # (slab buffer, out, M*N, splitk)
 
     def buffer(self, numel: int) -> torch.Tensor:
-        return self.ws.get(f"gemm_slabs_{len(self._items)}", numel)
+        return self.ws.get(f"gemm_slabs_{self.tag}{len(self._items)}", numel)
 
     def add(self, wbuf, out, total: int, splitk: int):
         self._items.append((wbuf, out, int(total), int(splitk)))
