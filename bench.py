@@ -219,6 +219,13 @@ def main():
     device = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(device)
     use_dist = world > 1 or bool(args.force_dist)
+    stdout_fd = None
+    if use_dist:
+        # RCCL prints a version banner (and gloo its connection lines) on the C-level stdout when a communicator comes
+        # up: everything but the result line goes to stderr, so that stdout carries the ONE JSON line and nothing else
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -447,7 +454,12 @@ def main():
         }
         if exchange_check is not None:
             out["exchange_check"] = exchange_check
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        if stdout_fd is not None:
+            os.dup2(2, 1)                       # whatever the teardown prints is not part of the result
     if use_dist:
         import gc
         import torch.distributed as dist

@@ -82,3 +82,24 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
         if not v.dtype.is_floating_point:
             continue
         torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("extra", [["--force-dist", "1"], ["--gpus", "2", "--rehearse-on-one-gpu", "1"]])
+def test_bench_stdout_is_one_json_line_when_a_communicator_comes_up(extra):
+    """RCCL prints a version banner and gloo its connection lines on the C-level stdout: the benchmark must keep them out
+    of its own stdout, which carries exactly the one result line (the real RCCL path with one rank; the two-rank
+    rehearsal through the self-launcher)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "512",
+                        "--hidden", "64,32", "--cpu-baseline", "0", "--event-pass", "0", "--distinct-batches", "2", *extra],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["exchange_check"] == "ok" and d["steps"] == 2
+    assert d["n_gpus"] == (2 if "--gpus" in extra else 1)
