@@ -620,41 +620,88 @@ __global__ __launch_bounds__(256) void chunk_reduce_colsum_kernel(ReduceArgs a, 
     else splitk_reduce_multi_body(sk, b - nsp - cs_blocks);       // weight-gradient slabs of the dense backward
 }
 
+// Sum of the chunk sums [c0, c1) of field f in chunk order, RU loads in flight (acc / acc1 start at zero).
+template <int VEC>
+__device__ __forceinline__ void add_chunk_sums(const ReduceArgs& a, int f, int c0, int c1, int cc, float (&acc)[VEC], float& acc1) {
+    const int d = a.d, co = cc * VEC;
+    for (int c = c0; c < c1; c += RU) {
+        float p[RU][VEC], p1[RU];
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) p[r][e] = 0.f;
+            p1[r] = 0.f;
+            if (c + r < c1) {
+                ldv<VEC>(a.chunk_sum + ((long long)f * a.cap + c + r) * d + co, p[r]);
+                if (cc == 0 && a.chunk_sum1) p1[r] = a.chunk_sum1[(long long)f * a.cap + c + r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RU; ++r) {          // chunk order: fixed summation order
+            if (c + r < c1) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += p[r][e];
+                acc1 += p1[r];
+            }
+        }
+    }
+}
+
+// A lane group (C lanes) adds the chunk sums of one distinct row in chunk order.  A row with more than HEAVY_CHUNKS
+// chunks (one value in more than HEAVY_CHUNKS * L entries of the batch: small vocabularies, large batches) would keep
+// its group busy long after the rest of the launch is done, so the groups of its wave share it: group j adds the j-th
+// of 64/C contiguous sub-ranges of its chunks, and the sub-range sums are added in sub-range order -- still a fixed
+// order, one that depends only on the plan.  (Needs lane groups that do not straddle waves: 64 % C == 0.)
+constexpr int HEAVY_CHUNKS = 48;
 template <int VEC>
 __device__ __forceinline__ void segment_finalize_body(const ReduceArgs& a, int f, int bx, int part_index, float* red) {
     const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
     const int gpb = 256 / a.C;
     const int u = bx * gpb + grp;
+    const bool coop = (64 % a.C) == 0;
+    const int lane = threadIdx.x & 63;
     float nsq = 0.f;
-    if (grp < gpb && u < a.counts[f * 4 + 2]) {
+    const bool mine = grp < gpb && u < a.counts[f * 4 + 2];
+    int c0 = 0, c1 = 0;
+    if (mine) {
         const int* sf = a.seg_first_chunk + (long long)f * (a.cap + 1);
-        const int c0 = sf[u], c1 = sf[u + 1];
-        const int d = a.d, co = cc * VEC;
-        float acc[VEC];
+        c0 = sf[u]; c1 = sf[u + 1];
+    }
+    const bool heavy = coop && (c1 - c0) > HEAVY_CHUNKS;
+    float acc[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-        float acc1 = 0.f;
-        for (int c = c0; c < c1; c += RU) {
-            float p[RU][VEC], p1[RU];
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    float acc1 = 0.f;
+    if (mine && !heavy) add_chunk_sums<VEC>(a, f, c0, c1, cc, acc, acc1);
+    if (coop && __any(heavy)) {                              // wave-uniform
+        const int gw = 64 / a.C, gl = lane / a.C;            // lane groups of this wave, this lane's group among them
+        for (int h = 0; h < gw; ++h) {
+            const int hl = h * a.C;                          // first lane of group h
+            if (!__shfl((int)heavy, hl, 64)) continue;       // wave-uniform
+            const int h0 = __shfl(c0, hl, 64), h1 = __shfl(c1, hl, 64);
+            const int per = (h1 - h0 + gw - 1) / gw;
+            const int s0 = min(h1, h0 + gl * per), s1 = min(h1, s0 + per);
+            float part[VEC], part1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < RU; ++r) {
+            for (int e = 0; e < VEC; ++e) part[e] = 0.f;
+            add_chunk_sums<VEC>(a, f, s0, s1, cc, part, part1);
+            float tot[VEC], tot1 = 0.f;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) p[r][e] = 0.f;
-                p1[r] = 0.f;
-                if (c + r < c1) {
-                    ldv<VEC>(a.chunk_sum + ((long long)f * a.cap + c + r) * d + co, p[r]);
-                    if (cc == 0 && a.chunk_sum1) p1[r] = a.chunk_sum1[(long long)f * a.cap + c + r];
-                }
+            for (int e = 0; e < VEC; ++e) tot[e] = 0.f;
+            for (int j = 0; j < gw; ++j) {                   // sub-range order
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tot[e] += __shfl(part[e], j * a.C + cc, 64);
+                tot1 += __shfl(part1, j * a.C, 64);
             }
+            if (gl == h) {
 #pragma unroll
-            for (int r = 0; r < RU; ++r) {          // chunk order: fixed summation order
-                if (c + r < c1) {
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[e] += p[r][e];
-                    acc1 += p1[r];
-                }
+                for (int e = 0; e < VEC; ++e) acc[e] = tot[e];
+                acc1 = tot1;
             }
         }
+    }
+    if (mine) {
+        const int d = a.d, co = cc * VEC;
         stv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, acc);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) nsq += acc[e] * acc[e];

@@ -80,6 +80,37 @@ def test_row_sets_and_row_grads(B, vocabs, d):
     assert torch.equal(grad, grad2)
 
 
+@pytest.mark.parametrize("B,vocabs,d", [(4096, [2, 3, 1000], 16), (16384, [2, 40], 16), (8192, [3, 2], 8), (4096, [2], 1),
+                                        (3000, [2, 5], 32), (4096, [2, 7], 20), (2048, [2], 64)])
+def test_rows_with_many_chunks(B, vocabs, d):
+    """One value in thousands of entries of a batch (a vocabulary of two or three rows): the row's chunk sums are added
+    by all lane groups of a wave (contiguous sub-ranges, combined in sub-range order) instead of one group alone; the
+    widths cover 1, 2, 4, 8 and 16 lanes per row and one (d = 20) whose lane groups straddle waves and keep the serial
+    form.  Row gradients and the norm against torch CPU, and bitwise repeatable."""
+    from recommendsystem_amd import ops
+    idx, g = _case(B, vocabs, seed=B + d, skew=False)
+    F = len(vocabs)
+    gout = torch.randn(B, F, d, generator=g)
+    want = _dense_ref(idx, vocabs, gout, d)
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    plan = ops.SparsePlan(layout, cap=B, d=d, with_lr=False)
+    grads = []
+    for _ in range(2):
+        plan.sort_columnar(idx.to(dev))
+        partials = torch.zeros(plan.n_partials, device=dev)
+        plan.reduce(partials, gout=gout.to(dev).view(B * F, d))
+        grad = torch.zeros(layout.total_rows, d, device=dev)
+        plan.scatter_dense(grad=grad)
+        grads.append(grad)
+    assert torch.equal(grads[0], grads[1])
+    c = plan.counts().cpu()
+    assert int(c[0, 1]) - int(c[0, 2]) > 48              # field 0 has a row of far more than 48 chunks
+    mag = _dense_ref(idx, vocabs, gout.abs(), d)
+    assert ((grads[0].cpu() - want).abs() <= 1e-6 * mag + 1e-30).all()
+    torch.testing.assert_close(partials.sum().cpu().double().sqrt(), want.double().norm(), rtol=1e-5, atol=1e-12)
+
+
 @pytest.mark.parametrize("B", [1025, 1500, 2048, 2049, 3000, 3073, 4095, 4096, 4097, 5000, 7000, 8192, 8193, 12345, 16384])
 def test_two_level_sort_writes_the_same_plan(B):
     """Lists of more than 1024 entries are sorted as tiles and merged (up to 4096 entries in one launch, the workgroup
