@@ -7,8 +7,8 @@
 namespace {
 
 // Several column-sum reductions in one launch: problem p adds the `rows[p]` partial rows part[p][r*ld[p] + n]
-// (n < n[p]) in row order into out[p][n].  16 columns per workgroup: thread (c = tid % 16, r = tid / 16) adds
-// rows r, r+16, ..., then the 16 row groups of a column meet in LDS.
+// (n < n[p]) in a fixed order into out[p][n].  16 columns per workgroup: thread (c = tid % 16, r = tid / 16) adds
+// rows r, r+16, ... (sixteen accumulators, combined pairwise), then the 16 row groups of a column meet in LDS.
 constexpr int CF_MAX = 8;
 struct ColsumFinishArgs {
     const float* part[CF_MAX]; float* out[CF_MAX];
@@ -23,15 +23,24 @@ __device__ __forceinline__ void colsum_finish_body(const ColsumFinishArgs& a, in
     const int n = (block - a.first_block[p]) * 16 + c;
     const float* part = a.part[p];
     const int rows = a.rows[p], ld = a.ld[p];
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < a.n[p]) {
-        for (int g = r; g < rows; g += 64) {
+    // 16 independent loads in flight per thread: with a thousand partial rows (a 1-wide head at batch 16384) and only
+    // n/16 workgroups, the loop is a chain of memory latencies, not a stream
+    constexpr int CF_U = 16;
+    float s[CF_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < CF_U; ++u) s[u] = 0.f;
+    if (n < a.n[p]) {
+        for (int g = r; g < rows; g += 16 * CF_U) {
+#pragma unroll
+            for (int u = 0; u < CF_U; ++u)
                 if (g + 16 * u < rows) s[u] += part[(long long)(g + 16 * u) * ld + n];
         }
     }
-    red[r][c] = (s[0] + s[1]) + (s[2] + s[3]);
+#pragma unroll
+    for (int w = CF_U / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) s[u] += s[u + w];
+    red[r][c] = s[0];
     __syncthreads();
     if (r == 0 && n < a.n[p]) {
         float t = 0.f;
