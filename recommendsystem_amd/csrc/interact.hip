@@ -556,21 +556,36 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_reg_kernel(const float* __r
     for (int l = 0; l < L; ++l)
 #pragma unroll
         for (int i = 0; i < T; ++i) accW[l][i] = accB[l][i] = 0.f;
-    for (int b = blockIdx.x * 4 + wv; b < B; b += gridDim.x * 4) {
-        const float* xs = x0 + (long long)b * D;
+    // The operands of the wave's next sample are requested before the current one is worked on: a sample is two
+    // dependent phases (memory latency, then L wave reductions), and a wave walks its samples one after the other.
+    const int bstep = gridDim.x * 4;
+    float nsv[L], nx0[T], ndx[T];
+    auto fetch = [&](int bb) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) nsv[l] = S[(long long)bb * L + l];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int n = lane + 64 * i;
+            nx0[i] = n < D ? x0[(long long)bb * D + n] : 0.f;
+            ndx[i] = n < D ? dout[(long long)bb * D + n] : 0.f;
+        }
+    };
+    const int b_first = blockIdx.x * 4 + wv;
+    if (b_first < B) fetch(b_first);
+    for (int b = b_first; b < B; b += bstep) {
         float sv[L];
 #pragma unroll
-        for (int l = 0; l < L; ++l) sv[l] = S[(long long)b * L + l];
+        for (int l = 0; l < L; ++l) sv[l] = nsv[l];
         float x0r[T], dx[T], d0[T];
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-            const int n = lane + 64 * i;
-            x0r[i] = n < D ? xs[n] : 0.f;
-            dx[i] = n < D ? dout[(long long)b * D + n] : 0.f;
+            x0r[i] = nx0[i];
+            dx[i] = ndx[i];
             d0[i] = 0.f;
-            if (n < D) part = fmaf(dx[i], x0r[i], part);
+            part = fmaf(dx[i], x0r[i], part);        // lanes past D hold zeros
         }
+        if (b + bstep < B) fetch(b + bstep);
 #pragma unroll
         for (int l = L - 1; l >= 0; --l) {
             const float ds = rs_wave_sum(part);
