@@ -203,20 +203,38 @@ __global__ __launch_bounds__(256) void pnn_inner_bwd_mfma_kernel(const float* __
             slot[I][s4] = (i < F && k < F && i != k) ? pair_index_any(i, k, F) : P;
         }
     if (lane == 0) gl[P] = 0.f;
-    for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < B; b += nwaves) {
-        const float* e = emb + (long long)b * fd;
-        const float* drow = dout + (long long)b * ld;
-        const float* gs = drow + (CAT ? fd : 0);
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < P; i += 64) gl[i] = gs[i];
-        float bv[KS][NC];
+    // A wave walks its samples one after the other, and a sample is memory latency followed by LDS gathers and matrix
+    // instructions: the next sample's dP row and E operands are requested (into registers) before the current one is
+    // worked on.
+    constexpr int NPR = (16 * NB * (16 * NB - 1) / 2 + 63) / 64;       // dP values per lane, at most
+    float pg[NPR], pbv[KS][NC];
+    auto fetch = [&](int bb) {
+        const float* e = emb + (long long)bb * fd;
+        const float* gs = dout + (long long)bb * ld + (CAT ? fd : 0);
+#pragma unroll
+        for (int i = 0; i < NPR; ++i) pg[i] = (lane + 64 * i < P) ? gs[lane + 64 * i] : 0.f;
 #pragma unroll
         for (int s4 = 0; s4 < KS; ++s4)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int k = 4 * s4 + g, col = 16 * c + r;
-                bv[s4][c] = (k < F && col < D) ? e[k * D + col] : 0.f;
+                pbv[s4][c] = (k < F && col < D) ? e[k * D + col] : 0.f;
             }
+    };
+    const int b_first = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b_first < B) fetch(b_first);
+    for (int b = b_first; b < B; b += nwaves) {
+        const float* drow = dout + (long long)b * ld;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NPR; ++i)
+            if (lane + 64 * i < P) gl[lane + 64 * i] = pg[i];
+        float bv[KS][NC];
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bv[s4][c] = pbv[s4][c];
+        if (b + nwaves < B) fetch(b + nwaves);
         __builtin_amdgcn_wave_barrier();
         float* o = demb + (long long)b * fd;
 #pragma unroll
