@@ -76,13 +76,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int
 
 // ---- stable LSD radix sort of the 1024*ITEMS items in buf, DB key bits per pass ---------------------
 // Items are taken striped (item j of thread t is element j*1024 + t), so the 64 lanes of a wave hold a
-// contiguous run of elements: one ballot per digit bit gives, for every digit value, the run's count
-// (lanes 0..NB-1 each build the mask of "their" value) and every lane's rank inside the run; an exclusive
-// scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that NB * runs = 1024.
+// contiguous run of elements: one ballot per digit bit gives every lane the mask of the lanes of its run that hold
+// the same digit value -- its rank inside the run, and, in the first lane of every such group, the run's count of that
+// value; an exclusive scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that
+// NB * runs = 1024.  Values a run does not hold keep the zero of a count array cleared during the previous pass (two
+// arrays alternate, so clearing needs no barrier of its own).
 template <int ITEMS> constexpr int radix_digit_bits() {
     return ITEMS == 1 ? 6 : (ITEMS == 2 ? 5 : (ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2)));
 }
-// passes over the key bits [bit_lo, nbits), bit_lo a multiple of the digit width
+// passes over the key bits [bit_lo, nbits), bit_lo a multiple of the digit width; scratch: [32] + 2 x [1024] ints
 template <int ITEMS>
 __device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scratch, int nbits, int bit_lo = 0) {
     constexpr int DB = radix_digit_bits<ITEMS>();
@@ -90,10 +92,15 @@ __device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scrat
     constexpr int G = 16 * ITEMS;                 // runs of 64 elements
     static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
     const int t = threadIdx.x;
-    int* cnt = scratch + 32;                      // [NB][G]
     const int lane = t & 63, w = t >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int bit = bit_lo; bit < nbits; bit += DB) {
+    if (bit_lo >= nbits) return;
+    int which = 0;
+    scratch[32 + t] = 0;
+    __syncthreads();
+    for (int bit = bit_lo; bit < nbits; bit += DB, which ^= 1) {
+        int* cnt = scratch + 32 + which * SORT_THREADS;              // [NB][G]
+        int* other = scratch + 32 + (which ^ 1) * SORT_THREADS;
         const int sh = 32 + bit;
         unsigned long long x[ITEMS], mk[ITEMS];
         int dg[ITEMS];
@@ -101,14 +108,13 @@ __device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scrat
         for (int j = 0; j < ITEMS; ++j) {
             x[j] = buf[j * SORT_THREADS + t];
             const int dgt = (int)((x[j] >> sh) & (unsigned long long)(NB - 1));
-            unsigned long long own = ~0ull, mine = ~0ull;      // mask of my digit / of digit value `lane`
+            unsigned long long own = ~0ull;                          // lanes of this run with my digit
 #pragma unroll
             for (int k = 0; k < DB; ++k) {
                 const unsigned long long mb = __ballot((dgt >> k) & 1);
                 own &= ((dgt >> k) & 1) ? mb : ~mb;
-                mine &= ((lane >> k) & 1) ? mb : ~mb;
             }
-            if (lane < NB) cnt[lane * G + j * 16 + w] = __popcll(mine);
+            if ((own & lt) == 0ull) cnt[dgt * G + j * 16 + w] = __popcll(own);
             dg[j] = dgt;
             mk[j] = own;
         }
@@ -117,6 +123,7 @@ __device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scrat
         int tot_unused;
         const int ex = block_excl_scan(v, scratch, &tot_unused);
         cnt[t] = ex;
+        other[t] = 0;                                                // the next pass counts into a cleared array
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -218,7 +225,7 @@ __device__ __forceinline__ void segment_tail(const SortArgs& a, int f, const uns
 template <int ITEMS>
 __device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*ITEMS]
-    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32] + [1024]
+    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32] + 2 x [1024]
     const int t = threadIdx.x;
     constexpr int CAPB = SORT_THREADS * ITEMS;
     const int nbits = key_bits(a.vocab[f]);
@@ -1039,7 +1046,7 @@ bool two_level_shape(int n, int nsrc, TwoLevelShape* s) {
 inline unsigned long long* plan_tiles(int* plan, int F, int cap) {
     return reinterpret_cast<unsigned long long*>(plan + (size_t)F * (6 * (size_t)cap + 2 + 4));
 }
-inline size_t sort_lds(int items) { return (size_t)SORT_THREADS * items * 8 + (32 + SORT_THREADS) * sizeof(int); }
+inline size_t sort_lds(int items) { return (size_t)SORT_THREADS * items * 8 + (32 + 2 * SORT_THREADS) * sizeof(int); }
 
 // launches 2 and 3 of the two-level sort
 int launch_rank_tail(const SortArgs& a, const TwoLevelShape& sh, unsigned long long* tiles64, hipStream_t stream) {
