@@ -674,7 +674,18 @@ __device__ __forceinline__ void segment_finalize_body(const ReduceArgs& a, int f
         const int* sf = a.seg_first_chunk + (long long)f * (a.cap + 1);
         c0 = sf[u]; c1 = sf[u + 1];
     }
-    const bool heavy = coop && (c1 - c0) > HEAVY_CHUNKS;
+    bool heavy = coop && (c1 - c0) > HEAVY_CHUNKS;
+    if (coop) {
+        // Sharing costs about one memory latency per shared row, one row after the other; the rows of a small vocabulary
+        // sit in one wave, and several long rows side by side (one per lane group) are then the faster form.
+        const unsigned long long hb = __ballot(heavy && cc == 0);
+        if (hb) {                                            // wave-uniform
+            int mx = c1 - c0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if (mx <= 24 * (int)__popcll(hb)) heavy = false;
+        }
+    }
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
