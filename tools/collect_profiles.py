@@ -45,8 +45,10 @@ def main():
     assert "us/step" in sb and "gemm_f32_dma_kernel" in sb, "step_breakdown.txt is not a step breakdown"
     t = json.load(open(os.path.join(src, "pmc_traffic.json")))
     assert any(k.startswith("gemm_f32_dma_kernel") for k in t["kernels"]) and any("gather" in k for k in t["kernels"])
+    mu = json.load(open(os.path.join(src, "mfma_util.json")))
+    assert any(k.startswith("gemm_f32") and v["SQ_INSTS_MFMA"] > 0 for k, v in mu["kernels"].items()), "mfma_util.json lacks the GEMM"
     for name in ("bench_n1.json", "bench_variants.jsonl", "interact_roofline.jsonl", "bench_kernel_stats.csv",
-                 "interact_kernel_stats.csv", "step_breakdown.txt", "pmc_traffic.json"):
+                 "interact_kernel_stats.csv", "step_breakdown.txt", "pmc_traffic.json", "mfma_util.json"):
         shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
         print("profiles/" + f"{rnd}_{name}")
     # bench.py reads the traffic counters from the newest round's file

@@ -62,5 +62,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py "$OUT" || exit 1
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write"
+
+step "matrix-core utilisation (one SQ counter pass, no tracing)"
+D=$OUT/pmc_sq
+mkdir -p "$D"
+( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU \
+    --output-format csv -d "$D" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$D/bench.json" 2> "$D/bench.err" ) || exit 1
+python tools/pmc_mfma.py "$OUT" || exit 1
+rm -rf "$OUT/pmc_sq"
 ls -la "$OUT"
 echo refreshed
