@@ -113,6 +113,9 @@ typedef struct rs_gemm_desc {
     int splitk;
     float* workspace; size_t workspace_bytes;
     float* colsum_part;
+    /* drop_p > 0 (splitk == 1 only): the mask of rs_gemm_f32_drop with this key is multiplied into the result */
+    float drop_p; unsigned drop_salt; unsigned long long drop_seed; unsigned long long drop_call_host;
+    const long long* drop_call_dev;
 } rs_gemm_desc;
 int rs_gemm_f32_group(const rs_gemm_desc* descs /* host array */, int count, int stages, rs_stream_t stream);
 /* out[p][n] = sum_{r < rows[p]} part[p][r*ld[p] + n] for n < n[p], p < count <= 8, in one launch.  The five arrays

@@ -33,7 +33,9 @@ class GemmDesc(C.Structure):
                 ("mulsrc", C.c_void_p), ("ldm", I), ("mul_act", I),
                 ("splitk", I),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("colsum_part", C.c_void_p)]
+                ("colsum_part", C.c_void_p),
+                ("drop_p", C.c_float), ("drop_salt", C.c_uint), ("drop_seed", C.c_ulonglong),
+                ("drop_call_host", C.c_ulonglong), ("drop_call_dev", C.c_void_p)]
 
 
 # name -> argtypes (every entry point returns int, except where noted below)

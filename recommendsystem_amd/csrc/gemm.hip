@@ -936,6 +936,9 @@ typedef struct rs_gemm_desc {
     int splitk;
     float* workspace; size_t workspace_bytes;
     float* colsum_part;
+    /* drop_p > 0 (splitk == 1 only): the mask of rs_gemm_f32_drop with this key is multiplied into the result */
+    float drop_p; unsigned drop_salt; unsigned long long drop_seed; unsigned long long drop_call_host;
+    const long long* drop_call_dev;
 } rs_gemm_desc;
 }
 
@@ -1097,6 +1100,7 @@ int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t 
         if (q.splitk > 1) {
             RS_CHECK_ARG(q.workspace && q.workspace_bytes >= rs_gemm_workspace_bytes(q.M, q.N, q.splitk),
                          "rs_gemm_f32_group: workspace of product %d too small for splitk=%d", p, q.splitk);
+            RS_CHECK_ARG(!(q.drop_p > 0.f), "rs_gemm_f32_group: a dropout mask goes with an unsplit product only");
             g.C = q.workspace; g.ldc = q.N; g.ws = q.workspace; g.defer = 1;
             g.vec_epi = (q.N % 4 == 0 && aligned16(q.workspace)) ? 1 : 0;
         } else {
@@ -1105,6 +1109,11 @@ int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t 
             RS_CHECK_ARG(q.act >= RS_ACT_NONE && q.act <= RS_ACT_LEAKYRELU, "rs_gemm_f32_group: activation %d not fusable", q.act);
             g.C = q.C; g.ldc = q.ldc; g.bias = q.bias; g.act = q.act; g.mulsrc = q.mulsrc; g.ldm = q.ldm;
             g.mul_act = q.mul_act; g.cs_part = q.colsum_part;
+            if (q.drop_p > 0.f) {
+                RS_CHECK_ARG(q.drop_p <= 1.f, "rs_gemm_f32_group: dropout probability has to be between 0 and 1, but got %f", (double)q.drop_p);
+                g.has_drop = 1;
+                g.drop = DropKey{q.drop_p, q.drop_salt, q.drop_seed, q.drop_call_host, q.drop_call_dev};
+            }
             g.vec_epi = (q.N % 4 == 0 && aligned16(q.C) && q.ldc % 4 == 0 && (!q.bias || aligned16(q.bias)) &&
                          (!q.mulsrc || (aligned16(q.mulsrc) && q.ldm % 4 == 0))) ? 1 : 0;
         }

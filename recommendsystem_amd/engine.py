@@ -525,9 +525,10 @@ class FusedTrainer:
                     # sums (the previous block's bias gradient) then come out of the same launch
                     if fuse_prev:
                         csp.expect(self.gviews[id(prev.fc.bias)])
-                    if grp is not None and mask_key is None:
+                    if grp is not None:
                         dh = grp.add(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
-                                     mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None)
+                                     mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,
+                                     dropout=mask_key)
                     else:
                         dh = ops.gemm(dzl, c.W, b_nc=True, mulsrc=cs[i - 1].h if fuse_prev else None,
                                       mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,

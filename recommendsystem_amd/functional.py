@@ -405,8 +405,8 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
             out["dx"] = ops.act_bwd(out["dx"].contiguous(), mul_act, h=mulsrc)[0]
         out["dz"] = dz
         return out
-    # dW and dx both need only dz: one launch for the two products (ops.GemmGroup), unless a dropout mask rides in dx
-    grp = ops.GemmGroup(ops.GROUP_STAGES) if (ops.GROUP_STAGES and need_dx and dx_dropout is None) else None
+    # dW and dx both need only dz: one launch for the two products (ops.GemmGroup)
+    grp = ops.GemmGroup(ops.GROUP_STAGES) if (ops.GROUP_STAGES and need_dx) else None
     if grp is not None:
         out["dW"] = grp.add(dz, c.x, a_mc=True, b_nc=True, out=dW_out, defer_reduce=defer_reduce)
     else:
@@ -417,13 +417,14 @@ def mlp_block_bwd(dh, c: MLPCtx, need_dx=True, dz_ready=False, dW_out=None, db_o
         if mulsrc is not None and colsum_parts is not None and dbp_out is not None:
             colsum_parts.expect(dbp_out)
             if grp is not None:
-                out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts)
+                out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts,
+                                    dropout=dx_dropout)
             else:
                 out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, colsum_part=colsum_parts,
                                      dropout=dx_dropout)
             out["dbp_left"] = True
         elif grp is not None:
-            out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act)
+            out["dx"] = grp.add(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, dropout=dx_dropout)
         else:
             out["dx"] = ops.gemm(dz, c.W, b_nc=True, mulsrc=mulsrc, mul_act=mul_act, dropout=dx_dropout)
         if grp is not None:

@@ -277,7 +277,7 @@ SORT_SPLIT_PASSES = int(os.environ.get("RS_SORT_SPLIT", "4"))
 class GemmGroup:
     """Products that may run in one launch (rs_gemm_f32_group): they wait for the same predecessor and nobody reads
     their results before the launch after them -- a layer's dX and dW.  add() takes the arguments of gemm() (64x64
-    tiles; no dropout, no accumulate); launch() issues everything collected, in groups of four.  A product the grouped
+    tiles; no accumulate); launch() issues everything collected, in groups of four.  A product the grouped
     kernel cannot take (operands that do not allow 16-byte accesses) is issued by gemm() right away."""
 
     def __init__(self, stages: int = 2):
@@ -289,7 +289,7 @@ class GemmGroup:
         return len(self._descs)
 
     def add(self, a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None, act=0, mulsrc=None, mul_act=0,
-            out=None, splitk=0, colsum_part=None, defer_reduce=None) -> torch.Tensor:
+            out=None, splitk=0, colsum_part=None, defer_reduce=None, dropout=None) -> torch.Tensor:
         lda = _chk_rows(a, "a")
         ldb = _chk_rows(b, "b")
         M, K = (a.shape[1], a.shape[0]) if a_mc else (a.shape[0], a.shape[1])
@@ -317,9 +317,10 @@ class GemmGroup:
         ok = ok and (M % 4 == 0 if a_mc else K % 4 == 0) and (N % 4 == 0 if b_nc else K % 4 == 0)
         split_ok = (defer_reduce is not None and bias is None and act == 0 and mulsrc is None and colsum_part is None
                     and out.is_contiguous())
-        if not ok or (splitk > 1 and not split_ok):
+        has_drop = dropout is not None and dropout[0] > 0
+        if not ok or (splitk > 1 and (not split_ok or has_drop)):
             return gemm(a, b, a_mc=a_mc, b_nc=b_nc, bias=bias, act=act, mulsrc=mulsrc, mul_act=mul_act, out=out,
-                        colsum_part=colsum_part, defer_reduce=defer_reduce)
+                        colsum_part=colsum_part, defer_reduce=defer_reduce, dropout=dropout)
         dsc = _lib.GemmDesc(a_mc=int(a_mc), b_nc=int(b_nc), M=M, N=N, K=K, A=a.data_ptr(), lda=lda, B=b.data_ptr(), ldb=ldb,
                             splitk=splitk)
         if splitk > 1:
@@ -338,6 +339,12 @@ class GemmGroup:
                 colsum_part.add(part, rows, N, N)
                 dsc.colsum_part = part.data_ptr()
                 self._keep.append(part)
+            if has_drop:
+                p_, seed, salt, call_no, call_dev = dropout
+                dsc.drop_p, dsc.drop_salt = float(p_), int(salt) & 0xFFFFFFFF
+                dsc.drop_seed, dsc.drop_call_host = int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_no)
+                dsc.drop_call_dev = call_dev.data_ptr() if call_dev is not None else None
+                self._keep.append(call_dev)
         self._descs.append(dsc)
         self._keep += [a, b, out, bias, mulsrc]
         return out

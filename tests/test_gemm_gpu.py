@@ -269,6 +269,19 @@ def test_grouped_products_equal_single_launches(stages):
     assert torch.equal(db2, db1)
     assert torch.equal(H2, H1)
     assert torch.equal(dWs2, dWs1)
+    # a dropout mask in the dX epilogue (mask regenerated from the key, then the act' factor): five products = two launches
+    key = (0.5, 1234, 7, 3, torch.full((1,), 2, dtype=torch.int64, device=DEV))
+    dXm1 = ops.gemm(dz, W, b_nc=True, mulsrc=hprev, mul_act=1, tile=5, splitk=1, dropout=key)
+    grp.add(dz, x, a_mc=True, b_nc=True, out=dW2, splitk=4, defer_reduce=sk2)
+    dXm2 = grp.add(dz, W, b_nc=True, mulsrc=hprev, mul_act=1, splitk=1, dropout=key)
+    grp.add(x, W, bias=bias, act=2, splitk=1)
+    grp.add(dzs, xs, a_mc=True, b_nc=True, splitk=1)
+    H3 = grp.add(x, W, bias=bias, act=1, splitk=1, dropout=key)
+    assert len(grp) == 5
+    grp.launch()
+    sk2.finish()
+    assert torch.equal(dXm2, dXm1) and bool((dXm2 == 0).any()) and not torch.equal(dXm2, dX1)
+    assert torch.equal(H3, ops.gemm(x, W, bias=bias, act=1, tile=5, splitk=1, dropout=key))
     # an operand that does not allow 16-byte accesses goes through a launch of its own
     a_odd = torch.randn(64, 33, generator=g).to(DEV)
     b_odd = torch.randn(48, 33, generator=g).to(DEV)
