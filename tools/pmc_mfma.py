@@ -6,7 +6,7 @@ SQ_VALU_MFMA_BUSY_CYCLES adds up, over all SIMDs, the cycles a matrix instructio
 Per kernel and launch:
   mfma_busy_per_simd_cycles = SQ_VALU_MFMA_BUSY_CYCLES / 1024            (256 CUs x 4 SIMDs)
   mfma_util_of_busy_cus     = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)
-  mfma_per_wave_share       = 4 * SQ_INSTS_MFMA-weighted issue cycles are not needed: SQ_INSTS_MFMA is printed raw
+SQ_INSTS_MFMA (matrix instructions issued, per wave) is kept raw.
 The wave-level counters (SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_VALU) count quad-cycles and are
 given as shares of SQ_WAVE_CYCLES."""
 import csv
