@@ -363,6 +363,9 @@ class SparseTrainer:
             self._partials = torch.zeros(n_total, dtype=torch.float32, device=self.device)
         P = self._partials
         off = 0
+        # one looked-up table set (every model but FFM): the dense gradient's norm partials come out of the embedding
+        # reduction's second launch and the flat dense step shares the touched-rows update's launch, as in the fused engine
+        single = len(jobs) == 1 and "ffm" not in jobs[0][0]
         for group, plan, n in jobs:
             idx = next(iter(group.values()))["idx"]
             B = idx.shape[1]
@@ -380,16 +383,20 @@ class SparseTrainer:
                     plan.sort_columnar(idx)
                 ge, gl = grad("emb"), grad("lr")
                 plan.reduce(P[off:off + n], gout=ge.view(B * plan.F, plan.d) if ge is not None else None,
-                            dlr=gl.view(B) if gl is not None else None)
+                            dlr=gl.view(B) if gl is not None else None,
+                            dense=self.flat_g if single else None,
+                            dense_partials=P[off + n:off + n + N_DENSE_PARTIALS] if single else None)
             if self.exact:
                 main = group.get("emb") or group.get("ffm")
                 for r in group.values():
                     self._group_of[id(r["holder"])] = {"plan": plan, "B": B, "main": main["holder"] if main else None,
                                                        "lr": group["lr"]["holder"] if "lr" in group else None}
             off += n
-        ops.sumsq_partials(self.flat_g, P[off:off + N_DENSE_PARTIALS])
+        if not single:
+            ops.sumsq_partials(self.flat_g, P[off:off + N_DENSE_PARTIALS])
         ops.clip_and_prepare(P, self.max_norm, self.scal, self.step_count, self.hyper)
-        ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
+        if not single:
+            ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
         for group, plan, n in jobs:
             st = {k: self._table_state(r["holder"]) for k, r in group.items()}
             if "ffm" in group:
@@ -398,9 +405,13 @@ class SparseTrainer:
             e, l = st.get("emb"), st.get("lr")
             if e is not None or l is not None:
                 flat = lambda t: t.view(-1) if t is not None else None
-                plan.update(self.opt, self.hyper, self.scal,
-                            table=e["w"] if e else None, m=e["m"] if e else None, v=e["v"] if e else None,
-                            table1=flat(l["w"]) if l else None, m1=flat(l["m"]) if l else None,
-                            v1=flat(l["v"]) if l else None, rs=e["rs"] if e else None, rs1=l["rs"] if l else None)
+                kw = dict(table=e["w"] if e else None, m=e["m"] if e else None, v=e["v"] if e else None,
+                          table1=flat(l["w"]) if l else None, m1=flat(l["m"]) if l else None,
+                          v1=flat(l["v"]) if l else None, rs=e["rs"] if e else None, rs1=l["rs"] if l else None)
+                if single:
+                    plan.update_with_dense(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m,
+                                           self.flat_v, **kw)
+                else:
+                    plan.update(self.opt, self.hyper, self.scal, **kw)
         self.last = {"records": cap.records, "direct_grads": len(cap._sunk)}
         return loss.detach()
