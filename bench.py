@@ -61,7 +61,9 @@ def parse():
     p.add_argument("--uniform", type=int, default=0, help="uniform instead of Zipf(1.1) indices")
     p.add_argument("--cpu-baseline", type=int, default=1)
     p.add_argument("--cpu-seconds", type=float, default=20.0)
-    p.add_argument("--distinct-batches", type=int, default=8)
+    p.add_argument("--distinct-batches", type=int, default=0,
+                   help="resident synthetic batches the steps cycle through; 0 (default) = warmup + steps, i.e. no batch "
+                        "is seen twice, so every step meets rows that are as stale as a first pass over the data makes them")
     p.add_argument("--force-dist", type=int, default=0,
                    help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
                         "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
@@ -143,18 +145,19 @@ def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
         x = {c: idx[j] for j, c in enumerate(cols)}
         O.train_step(m, opt, x, lab_cpu[i % len(lab_cpu)])
 
-    one(0)
-    one(1)
+    n_warm = 10
+    for i in range(n_warm):
+        one(i)
     t0 = time.perf_counter()
     n = 0
     while True:
-        one(n + 2)
+        one(n + n_warm)
         n += 1
         el = time.perf_counter() - t0
         if el >= args.cpu_seconds or n >= 50:
             break
     return {"value": n * args.batch / el, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of batch {args.batch} after 2 warm-up steps, same synthetic batches, "
+            "sample": f"{n} steps of batch {args.batch} after {n_warm} warm-up steps, same synthetic batches, "
                       f"torch CPU ops with {cores} threads ({el:.1f} s)"}
 
 
@@ -254,7 +257,7 @@ def main():
     else:
         eng = model.use_sparse_step(use_graph=bool(args.graph), exact_adam=bool(args.exact_adam))
 
-    nb = max(1, args.distinct_batches)
+    nb = args.distinct_batches if args.distinct_batches > 0 else args.warmup + args.steps
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
     idx_dev = [t.to(device) for t in idxs]
     lab_dev = [t.to(device) for t in labs]
@@ -264,15 +267,20 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # the pre-staged batches stay resident: with --graph one graph per batch buffer, replayed without copies
-    for i in range(max(args.warmup, nb if eng.use_graph else 0)):
+    # The pre-staged batches stay resident: with --graph one graph per batch buffer, replayed without copies.  The
+    # graphs are captured first (capturing leaves the training state as it was), so that the W warm-up steps and the K
+    # timed steps walk through W + K different batches when that many are resident (the default).
+    if eng.use_graph and hasattr(eng, "prepare"):
+        for b in range(nb):
+            eng.prepare(idx_dev[b], lab_dev[b])
+    for i in range(args.warmup):
         eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
 
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(args.warmup, args.warmup + args.steps):
         loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
     torch.cuda.synchronize()
     barrier()
@@ -442,6 +450,7 @@ def main():
                              "(the reference's dense optimizer)" if getattr(eng, "exact", False)
                              else "sparse, lazy: absent rows keep weights and moments"),
                        "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
+                       "distinct_batches": nb,
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": "single GPU" if world == 1 else (
                            f"dp{world} + replicated tables (RCCL all-gather of (row, gradient) pairs)"

@@ -684,6 +684,15 @@ class FusedTrainer:
         ent["graph"].replay()
         return ent["loss"]
 
+    def prepare(self, idx: torch.Tensor, labels: torch.Tensor):
+        """use_graph: capture the step of a resident batch (step_tensors(idx, labels, resident=True)) now, without
+        stepping; the training state is left as it was."""
+        if not self.use_graph:
+            return
+        key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(idx, labels)
+
     def _capture(self, idx, labels):
         """Capture one step reading `idx`/`labels` in place; the model state is left untouched."""
         ent = {"idx": idx, "labels": labels}

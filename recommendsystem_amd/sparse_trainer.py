@@ -225,6 +225,15 @@ class SparseTrainer:
         ent["graph"].replay()
         return ent["loss"]
 
+    def prepare(self, idx: torch.Tensor, labels: torch.Tensor):
+        """use_graph: capture the step of a resident batch (step_tensors(idx, labels, resident=True)) now, without
+        stepping; model and optimizer state are left as they were."""
+        if not self.use_graph:
+            return
+        key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(idx, labels)
+
     def _tick(self):
         self._unchecked += 1
         if self.check_every and self._unchecked >= self.check_every:
