@@ -64,6 +64,11 @@ def parse():
     p.add_argument("--distinct-batches", type=int, default=0,
                    help="resident synthetic batches the steps cycle through; 0 (default) = warmup + steps, i.e. no batch "
                         "is seen twice, so every step meets rows that are as stale as a first pass over the data makes them")
+    p.add_argument("--ahead", type=int, default=0,
+                   help="1 = announce every next batch to the step before it (step_tensors(..., next_idx=...)): its index "
+                        "sort rides in two backward GEMM launches and its Adam catch-up beside the update, as a feeder that "
+                        "stages batches ahead allows; 0 (default, measured faster: beside GEMM workgroups the sort runs "
+                        "three to five times as long as alone) = every step prepares its own batch in front of its lookup")
     p.add_argument("--force-dist", type=int, default=0,
                    help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
                         "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
@@ -270,18 +275,24 @@ def main():
     # The pre-staged batches stay resident: with --graph one graph per batch buffer, replayed without copies.  The
     # graphs are captured first (capturing leaves the training state as it was), so that the W warm-up steps and the K
     # timed steps walk through W + K different batches when that many are resident (the default).
+    use_next = bool(args.ahead) and hasattr(eng, "_ahead_supported") and eng._ahead_supported(args.batch)
+
+    def announce(i):
+        return {"next_idx": idx_dev[(i + 1) % nb]} if use_next else {}
+
     if eng.use_graph and hasattr(eng, "prepare"):
-        for b in range(nb):
-            eng.prepare(idx_dev[b], lab_dev[b])
+        for i in range(args.warmup + args.steps):
+            kw = dict(announce(i), ahead_slot=(i % 2) if i > 0 else None) if use_next else {}
+            eng.prepare(idx_dev[i % nb], lab_dev[i % nb], **kw)
     for i in range(args.warmup):
-        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
+        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True, **announce(i))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
 
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True)
+        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True, **announce(i))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -450,7 +461,7 @@ def main():
                              "(the reference's dense optimizer)" if getattr(eng, "exact", False)
                              else "sparse, lazy: absent rows keep weights and moments"),
                        "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
-                       "distinct_batches": nb,
+                       "distinct_batches": nb, "next_batch_announced": bool(use_next),
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": "single GPU" if world == 1 else (
                            f"dp{world} + replicated tables (RCCL all-gather of (row, gradient) pairs)"

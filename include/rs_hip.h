@@ -118,6 +118,18 @@ typedef struct rs_gemm_desc {
     const long long* drop_call_dev;
 } rs_gemm_desc;
 int rs_gemm_f32_group(const rs_gemm_desc* descs /* host array */, int count, int stages, rs_stream_t stream);
+/* rs_gemm_f32_group (3 ring stages) whose launch also carries rs_sparse_bwd_sort of a columnar batch idx [F, B]
+ * (arguments as for rs_sort_gather; B <= rs_group_sort_max_entries()): the index bookkeeping that the backward of the
+ * NEXT batch needs (Layers.py:137-160 under autograd) depends on nothing but that batch, keeps one workgroup per field
+ * busy and fits the LDS of a GEMM workgroup, so it rides beside a block's backward products instead of standing in
+ * front of a step.  count may be 0.  The plan written is rs_sparse_bwd_sort's, bit for bit.  phase 0: the whole sort;
+ * phase 1 / 2: its first split_passes radix passes in one launch (items parked in the plan's scratch), the rest and
+ * the plan in a later one -- beside GEMM workgroups a sort workgroup runs several times as long as alone. */
+int rs_group_sort_max_entries(void);
+int rs_gemm_f32_group_sort(const rs_gemm_desc* descs /* host array */, int count, const int64_t* idx, const int* sub_off,
+                           const int* sub_cnt, const int* pay_base, int cap, int L, const int64_t* vocab,
+                           const int64_t* row_offset, int* plan, int B, int F, int phase, int split_passes,
+                           rs_stream_t stream);
 /* out[p][n] = sum_{r < rows[p]} part[p][r*ld[p] + n] for n < n[p], p < count <= 8, in one launch.  The five arrays
  * are HOST arrays (of device pointers / sizes). */
 int rs_colsum_finish_multi(const float* const* part, const int* rows, const int* n, const int* ld, float* const* out,
@@ -441,6 +453,24 @@ int rs_sort_catchup(const int64_t* idx, const int* sub_off, const int* sub_cnt, 
                     const float* hyper, const float* bctab, int tab_n, int kmax, int split_passes, rs_stream_t stream);
 int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, int d, int opt, const long long* step,
                   const float* hyper, const float* bctab, int tab_n, int kmax, rs_stream_t stream);
+/* The replay for the DISTINCT rows of a sorted batch (`plan` of rs_sparse_bwd_sort, F fields of capacity cap) -- no
+ * atomics, a plan names a row once -- with the rows promised to the update that steps them next:
+ *   mode 0: every row of the plan whose stamp is below *step is brought up to *step steps, and all rows of the plan are
+ *           stamped *step + 1; the update that follows is then given no stamps to write (last = last1 = NULL).
+ *   mode 1: the promise is taken back (stamps above *step return to *step) when that update does not come.
+ * rs_sparse_dense_update_ahead is rs_sparse_dense_update (without stamps) with mode 0 for `next_plan`, the sorted plan
+ * of the batch the NEXT step trains on, in the same launch: the rows `plan` steps carry the stamp *step from the
+ * promise made to this update, so the replay leaves them alone, and every other row of the next batch is not touched
+ * by the update.  What the reference's dense optimizer does to rows a batch does not touch (BaseModel.py:149) thus
+ * costs a step no launch in front of its lookup. */
+int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
+                         float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
+                         const float* bctab, int tab_n, int kmax, int mode, rs_stream_t stream);
+int rs_sparse_dense_update_ahead(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                                 float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
+                                 const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
+                                 const float* scal, const int* next_plan, int* last, int* last1, const long long* step,
+                                 const float* bctab, int tab_n, int kmax, rs_stream_t stream);
 
 
 /* ---- row-sharded tables: device side of the all-to-all exchange (no reference counterpart: the

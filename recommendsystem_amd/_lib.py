@@ -56,6 +56,8 @@ _SIGS = {
     "rs_colsum_f32_noalloc": [c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_gemm_f32_slabs": [I, I, I, I, I, c_f32p, I, c_f32p, I, I, I, c_f32p, SZ, c_stream],
     "rs_gemm_f32_group": [C.c_void_p, I, I, c_stream],
+    "rs_gemm_f32_group_sort": [C.c_void_p, I, c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, I, I, I, I,
+                               c_stream],
     "rs_splitk_reduce_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     "rs_colsum_finish_multi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
     # sparse.hip
@@ -87,6 +89,11 @@ _SIGS = {
                               c_f32p, c_i32p, I, c_i64p, I, c_f32p, c_f32p, I, I, c_stream],
     "rs_sort_catchup": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p,
                         c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p, c_f32p, c_f32p, I, I, I, c_stream],
+    "rs_adam_catchup_plan": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p,
+                             c_f32p, c_f32p, I, I, I, c_stream],
+    "rs_sparse_dense_update_ahead": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                     c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i64p,
+                                     c_f32p, I, I, c_stream],
     "rs_adam_flush": [c_f32p, c_f32p, c_f32p, c_i32p, L, I, I, c_i64p, c_f32p, c_f32p, I, I, c_stream],
     # elementwise.hip
     "rs_bce_head": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, I, c_f32p, c_f32p, c_f32p, c_f32p, F,
@@ -162,6 +169,7 @@ _PLAIN = {
     "rs_pnn_outer_mlp_blocks": (I, [I, I, I, L]),
     "rs_pnn_inner_cat_ok": (I, [I, I]),
     "rs_sort_max_entries": (I, []),
+    "rs_group_sort_max_entries": (I, []),
     "rs_merge_max_entries": (I, []),
     "rs_sort_split_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),

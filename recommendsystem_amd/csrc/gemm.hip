@@ -25,6 +25,8 @@
 #include "philox.h"
 #include "colsum_finish.h"
 #include "splitk_multi.h"
+#include "plan.h"
+#include "sort_body.h"
 #include <stdlib.h>
 #include <atomic>
 #include <type_traits>
@@ -733,10 +735,9 @@ struct GemmGroupArgs {
     int count;
 };
 
+// workgroup b of a grouped launch
 template <int NST>
-__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x;
+__device__ __forceinline__ void group_block(const GemmGroupArgs& a, int b, float* smem) {
     int p = 0;
 #pragma unroll
     for (int q = 1; q < GROUP_MAX; ++q)
@@ -756,6 +757,46 @@ __global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs a) {
     if (lay == 0) gemm_dma_body<64, 64, false, false, NST>(a.g[p], bk, smem);
     else if (lay == 1) gemm_dma_body<64, 64, false, true, NST>(a.g[p], bk, smem);
     else gemm_dma_body<64, 64, true, true, NST>(a.g[p], bk, smem);
+}
+
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    group_block<NST>(a, blockIdx.x, smem);
+}
+
+// A grouped launch whose first `lead` workgroups (a multiple of 8, so that the products keep their XCDs) sort the index
+// lists of the NEXT batch, one field each (sort_body.h, 256 threads): the sort needs nothing but that batch, takes F
+// workgroups for some tens of microseconds and fits the LDS a GEMM workgroup has anyway -- beside a block's backward
+// products it costs the step nothing, where a launch of its own is that long on 39 of the 256 compute units.
+// The sort workgroup shares its compute unit with two GEMM workgroups whose waves mostly wait for the matrix pipeline:
+// at equal priority they still take two thirds of the issue slots and the sort -- one wave per SIMD, bound by
+// instruction issue -- takes three times as long as alone, longer than the products it rides with.  With priority its
+// short vector / scalar / LDS instructions go first and cost the matrix pipeline nothing it would have used.
+template <int ITEMS>
+__device__ __forceinline__ void sort_rider(const SortArgs* sa, int f, unsigned long long* buf) {
+    __builtin_amdgcn_s_setprio(3);
+#ifdef RS_SORT_TIMING
+    const unsigned long long t0 = wall_clock64();
+#endif
+    field_sort_body<ITEMS, 256>(*sa, f, buf);
+#ifdef RS_SORT_TIMING
+    if (threadIdx.x == 0) {           // behind the spilled items of all fields (experiment builds only)
+        unsigned long long* dbg = sa->spill + (size_t)sa->F * sa->cap + (sa->phase == 2 ? 2 * sa->F : 0);
+        dbg[2 * f] = t0; dbg[2 * f + 1] = wall_clock64();
+    }
+#endif
+}
+
+template <int NST, int ITEMS>
+__global__ __launch_bounds__(256) void gemm_f32_group_sort_kernel(GemmGroupArgs a, SortArgs sa, int lead) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < lead) {
+        if (b < sa.F) sort_rider<ITEMS>(&sa, b, reinterpret_cast<unsigned long long*>(smem));
+        return;
+    }
+    group_block<NST>(a, b - lead, smem);
 }
 
 // Sum the split-K slabs in slab order and apply the epilogue.
@@ -1073,12 +1114,12 @@ int rs_gemm_f32_slabs(int a_mc, int b_nc, int M, int N, int K, const float* A, i
 // C) or as for rs_gemm_f32_slabs (splitk > 1: slabs left in its workspace, C and the epilogue fields unused).  All
 // operands must allow 16-byte accesses (the condition under which rs_gemm_f32 takes its DMA kernel).  The caller
 // orders nothing between the products: they must not read one another's results.
-int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t stream) {
+// descriptors -> kernel arguments; *blocks = workgroups of the products (0: nothing to do)
+static int group_fill(GemmGroupArgs& a, const rs_gemm_desc* d, int count, int* blocks_out) {
+    *blocks_out = 0;
     RS_CHECK_ARG(count >= 0 && count <= GROUP_MAX, "rs_gemm_f32_group: at most %d products", GROUP_MAX);
-    RS_CHECK_ARG(stages >= 2 && stages <= 4, "rs_gemm_f32_group: 2, 3 or 4 ring stages");
     if (count == 0) return RS_OK;
     RS_CHECK_ARG(d, "rs_gemm_f32_group: null argument");
-    GemmGroupArgs a{};
     int next = 0, used = 0;
     for (int p = 0; p < count; ++p) {
         const rs_gemm_desc& q = d[p];
@@ -1130,6 +1171,16 @@ int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t 
     if (used == 0) return RS_OK;
     a.count = used;
     a.first[used] = next;
+    *blocks_out = next;
+    return RS_OK;
+}
+
+int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t stream) {
+    RS_CHECK_ARG(stages >= 2 && stages <= 4, "rs_gemm_f32_group: 2, 3 or 4 ring stages");
+    GemmGroupArgs a{};
+    int next = 0;
+    const int rc = group_fill(a, d, count, &next);
+    if (rc != RS_OK || next == 0) return rc;
     const size_t smem = (size_t)stages * (64 + 64) * 32 * sizeof(float);
     auto kern = stages == 2 ? gemm_f32_group_kernel<2> : stages == 3 ? gemm_f32_group_kernel<3> : gemm_f32_group_kernel<4>;
     static bool attr_set[3] = {false, false, false};
@@ -1143,6 +1194,54 @@ int rs_gemm_f32_group(const rs_gemm_desc* d, int count, int stages, hipStream_t 
     }
     hipLaunchKernelGGL(kern, dim3(next), dim3(256), smem, stream, a);
     RS_CHECK_LAUNCH("rs_gemm_f32_group");
+    return RS_OK;
+}
+
+// rs_gemm_f32_group (3 ring stages) with rs_sparse_bwd_sort of a columnar batch idx [F, B] (B <= rs_group_sort_max_entries())
+// riding in the same launch: the sort of the NEXT batch beside a block's backward products.  Arguments after `count`
+// as for rs_sort_gather.  count may be 0 (then only the sort runs).  phase 0: the whole sort; phase 1: its first
+// split_passes radix passes (4 key bits each above 1024 entries per field, 6 below), the items parked in the plan's
+// scratch; phase 2 (same split_passes, a later launch): the remaining passes and the plan.  A sort workgroup that
+// shares its compute unit with GEMM workgroups runs three to four times as long as alone, so the two halves ride
+// in two launches where there are two.
+int rs_group_sort_max_entries(void) { return 256 * 16; }
+
+int rs_gemm_f32_group_sort(const rs_gemm_desc* d, int count, const int64_t* idx, const int* sub_off, const int* sub_cnt,
+                           const int* pay_base, int cap, int L, const int64_t* vocab, const int64_t* row_offset, int* plan,
+                           int B, int F, int phase, int split_passes, hipStream_t stream) {
+    RS_CHECK_ARG(idx && sub_off && sub_cnt && pay_base && vocab && row_offset && plan, "rs_gemm_f32_group_sort: null argument");
+    RS_CHECK_ARG(B > 0 && F > 0 && L > 0 && cap >= B, "rs_gemm_f32_group_sort: bad sizes");
+    RS_CHECK_ARG(B <= 256 * 16, "rs_gemm_f32_group_sort: %d entries per field exceed %d", B, 256 * 16);
+    RS_CHECK_ARG(phase >= 0 && phase <= 2 && (phase == 0 || split_passes > 0), "rs_gemm_f32_group_sort: bad phase");
+    GemmGroupArgs a{};
+    int next = 0;
+    const int rc = group_fill(a, d, count, &next);
+    if (rc != RS_OK) return rc;
+    SortArgs sa{};
+    sa.keys = idx; sa.sub_off = sub_off; sa.sub_cnt = sub_cnt; sa.pay_base = pay_base; sa.pay_stride = F;
+    sa.nsrc = 1; sa.F = F; sa.cap = cap; sa.L = L; sa.vocab = vocab; sa.row_offset = row_offset;
+    const PlanView pv = carve_plan(plan, F, cap);
+    sa.sorted_src = pv.sorted_src; sa.entry_chunk = pv.entry_chunk; sa.entry_seg = pv.entry_seg;
+    sa.chunk_start = pv.chunk_start; sa.seg_row = pv.seg_row; sa.seg_first_chunk = pv.seg_first_chunk;
+    sa.counts = pv.counts;
+    sa.phase = phase; sa.split_passes = split_passes;
+    sa.spill = reinterpret_cast<unsigned long long*>(plan + (size_t)F * (6 * (size_t)cap + 2 + 4));   // the plan's tile scratch
+    const int lead = (F + 7) / 8 * 8;
+    const int items = B <= 1024 ? 4 : 16;
+    const size_t gsm = (size_t)3 * (64 + 64) * 32 * sizeof(float), ssm = sort_lds(items, 256);
+    const size_t smem = gsm > ssm ? gsm : ssm;
+    auto kern = items == 4 ? gemm_f32_group_sort_kernel<3, 4> : gemm_f32_group_sort_kernel<3, 16>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[items == 16]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) {
+            rs_set_error("rs_gemm_f32_group_sort: cannot raise dynamic LDS limit to %zu", smem);
+            return RS_ERR_LAUNCH;
+        }
+        attr_set[items == 16] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(lead + next), dim3(256), smem, stream, a, sa, lead);
+    RS_CHECK_LAUNCH("rs_gemm_f32_group_sort");
     return RS_OK;
 }
 

@@ -192,6 +192,100 @@ __device__ __forceinline__ void catchup_block(const CatchArgs& a, int block, int
     else catchup_body<1, NT>(a, t, block % per_table, &s_n, s_row, s_last);
 }
 
+// ---- the same replay for the DISTINCT rows of a sorted batch (the plan of the sparse backward) -------------------
+// Every row appears once in the plan's seg_row lists, so nobody has to be elected: the thread that looks at a row is
+// its only writer.  Used for the batch AFTER the one being stepped ("ahead"): with c = *step optimizer steps
+// complete once the launch that carries this code has ended (its own update included),
+//   last[row] <  c : the row is not part of the batch being stepped (whose rows carry last == c, see below) and is
+//                    brought from last[row] to c steps here;
+//   then last[row] = c + 1 for every row of the plan: a promise that the next update steps it, which is also what
+//                    tells the catch-up after that one that the row is in good hands.  The update therefore leaves the
+//                    stamps alone in this mode, and runs beside this code without touching the same rows' moments.
+// mode 1 takes the promise back (last[row] > c -> c) when the batch the plan was made for does not come.
+struct SegCatchArgs {
+    const int* seg_row; const int* counts;      // [F, cap] rows of the distinct keys, [F, 4] (n, chunks, segments, padding)
+    int F, cap;
+    RowTab t[2]; int nt;
+    int opt; const long long* step;
+    const float* hyper; const float* bctab; int tab_n; int kmax;
+    int mode;
+};
+
+// rows a workgroup of NT threads serves: one per group of C lanes (C = lanes of a row of the first table)
+inline int seg_rows_per_block(int d0, int NT) {
+    const int C = d0 % 4 == 0 ? d0 / 4 : d0;
+    return NT / C > 0 ? NT / C : 1;
+}
+
+// Workgroup bx of the ceil(cap / rows per block) that serve field f.  A group of C lanes per distinct row: every lane
+// reads the row's stamps, replays its slice of the first table (VEC floats; lane 0 of the group also the 1-dim second
+// table), lane 0 writes the new stamps.  The operands of both tables are requested before either is replayed.
+template <int VEC, int NT>
+__device__ __forceinline__ void catchup_seg_block(const SegCatchArgs& a, int f, int bx) {
+    const RowTab t0 = a.t[0];
+    const int C = t0.d / VEC;
+    const int rpb = NT / C > 0 ? NT / C : 1;
+    const int nseg = a.counts[f * 4 + 2];
+    if (bx * rpb >= nseg) return;                                   // uniform over the workgroup
+    const int grp = threadIdx.x / C, cc = threadIdx.x - grp * C;
+    const int u = bx * rpb + grp;
+    const bool act = grp < rpb && u < nseg;
+    const int c = (int)*a.step;
+    int row = 0, l0 = c, l1 = c;
+    if (act) {
+        row = a.seg_row[(long long)f * a.cap + u];
+        l0 = t0.last[row];
+        if (a.nt > 1) l1 = a.t[1].last[row];
+    }
+    __syncthreads();                                                // every lane of a row has read its stamps before they change
+    if (!act) return;
+    if (a.mode == 1) {
+        if (cc == 0) {
+            if (l0 > c) t0.last[row] = c;
+            if (a.nt > 1 && l1 > c) a.t[1].last[row] = c;
+        }
+        return;
+    }
+    const bool r0 = l0 < c, r1 = a.nt > 1 && cc == 0 && l1 < c;
+    if (r0 || r1) {
+        const ReplayConsts k = load_consts(a.hyper, a.opt, a.bctab, a.tab_n, a.kmax);
+        const long long o = (long long)row * t0.d + cc * VEC;
+        float w[VEC], m[VEC], v[VEC], w1[1], m1[1], v1[1];
+        if (r0) { row_ld<VEC>(t0.w + o, w); row_ld<VEC>(t0.m + o, m); row_ld<VEC>(t0.v + o, v); }
+        if (r1) { w1[0] = a.t[1].w[row]; m1[0] = a.t[1].m[row]; v1[0] = a.t[1].v[row]; }
+        if (r0) {
+            replay_zero_grad_steps<VEC>(k, w, m, v, l0, c - l0);
+            row_st<VEC>(t0.w + o, w); row_st<VEC>(t0.m + o, m); row_st<VEC>(t0.v + o, v);
+        }
+        if (r1) {
+            replay_zero_grad_steps<1>(k, w1, m1, v1, l1, c - l1);
+            a.t[1].w[row] = w1[0]; a.t[1].m[row] = m1[0]; a.t[1].v[row] = v1[0];
+        }
+    }
+    if (cc == 0) {
+        t0.last[row] = c + 1;
+        if (a.nt > 1) a.t[1].last[row] = c + 1;
+    }
+}
+
+inline int fill_seg_catchup(SegCatchArgs& a, const int* seg_row, const int* counts, int F, int cap, int d, float* table,
+                            float* m, float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt,
+                            const long long* step, const float* hyper, const float* bctab, int tab_n, int kmax, int mode) {
+    a.seg_row = seg_row; a.counts = counts; a.F = F; a.cap = cap;
+    int nt = 0;
+    if (table) {
+        if (!(m && v && last) || !(d >= 1 && ((d % 4 == 0 && d / 4 <= 256) || d <= 64))) return -1;
+        a.t[nt++] = RowTab{table, m, v, last, d};
+    }
+    if (table1) {
+        if (!(m1 && v1 && last1)) return -1;
+        a.t[nt++] = RowTab{table1, m1, v1, last1, 1};
+    }
+    a.nt = nt;
+    a.opt = opt; a.step = step; a.hyper = hyper; a.bctab = bctab; a.tab_n = tab_n; a.kmax = kmax; a.mode = mode;
+    return nt;
+}
+
 // fills a.t[] / scalars from entry-point arguments; returns the number of tables or -1
 inline int fill_catchup(CatchArgs& a, const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, int B, int F, int d,
                         float* table, float* m, float* v, int* last, float* table1, float* m1, float* v1, int* last1, int opt,

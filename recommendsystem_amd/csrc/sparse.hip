@@ -23,244 +23,10 @@
 #include "gather_body.h"
 #include "splitk_multi.h"
 #include "plan.h"
+#include "sort_body.h"
 
 namespace {
 
-constexpr int SORT_THREADS = 1024;
-
-struct SortArgs {
-    const int64_t* keys;      // index storage (int64, as the reference's .long() batches)
-    const int* sub_off;       // [nsrc*F] start of sub-list (s, f) inside keys
-    const int* sub_cnt;       // [nsrc*F] entries in sub-list (s, f)
-    const int* pay_base;      // [nsrc*F] gradient-row index of the first entry of sub-list (s, f)
-    int pay_stride;           // gradient-row index step between consecutive entries
-    int nsrc, F, cap, L;
-    const int64_t* vocab;     // [F]
-    const int64_t* row_offset;// [F]
-    int* sorted_src;          // [F, cap]   gradient-row index of the i-th entry in key order
-    int* entry_chunk;         // [F, cap]   chunk of the i-th entry in key order (-1: padding entry)
-    int* entry_seg;           // [F, cap]   segment (distinct row) of the i-th entry (-1: padding entry)
-    int* chunk_start;         // [F, cap+1] first sorted position of each chunk (+ sentinel)
-    int* seg_row;             // [F, cap]   stacked-table row of each segment
-    int* seg_first_chunk;     // [F, cap+1] first chunk of each segment (+ sentinel)
-    int* counts;              // [F, 4]     n, n_chunk, n_seg, n_padding
-    // A one-workgroup sort may be cut in two launches (each beside other work that needs only the batch):
-    // phase 1 loads the lists, runs the first split_passes radix passes and leaves the items in spill [F, cap];
-    // phase 2 picks them up, runs the remaining passes and writes the plan.  phase 0: the whole sort.
-    int phase, split_passes;
-    unsigned long long* spill;
-};
-
-// Exclusive scan of one int per thread over the 1024-thread workgroup; *total gets the sum.
-__device__ __forceinline__ int block_excl_scan(int v, int* scratch /*[17]*/, int* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    __syncthreads();                       // scratch may still be read from a previous call
-    if (lane == 63) scratch[w] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < SORT_THREADS / 64; ++i) {
-        const int s = scratch[i];
-        if (i < w) base += s;
-        tot += s;
-    }
-    *total = tot;
-    return base + inc - v;
-}
-
-// ---- stable LSD radix sort of the 1024*ITEMS items in buf, DB key bits per pass ---------------------
-// Items are taken striped (item j of thread t is element j*1024 + t), so the 64 lanes of a wave hold a
-// contiguous run of elements: one ballot per digit bit gives every lane the mask of the lanes of its run that hold
-// the same digit value -- its rank inside the run, and, in the first lane of every such group, the run's count of that
-// value; an exclusive scan over the NB x (runs) counts, one per thread, gives the bases.  DB is chosen so that
-// NB * runs = 1024.  Values a run does not hold keep the zero of a count array cleared during the previous pass (two
-// arrays alternate, so clearing needs no barrier of its own).
-template <int ITEMS> constexpr int radix_digit_bits() {
-    return ITEMS == 1 ? 6 : (ITEMS == 2 ? 5 : (ITEMS == 4 ? 4 : (ITEMS == 8 ? 3 : 2)));
-}
-// passes over the key bits [bit_lo, nbits), bit_lo a multiple of the digit width; scratch: [32] + 2 x [1024] ints
-template <int ITEMS>
-__device__ __forceinline__ void radix_passes(unsigned long long* buf, int* scratch, int nbits, int bit_lo = 0) {
-    constexpr int DB = radix_digit_bits<ITEMS>();
-    constexpr int NB = 1 << DB;
-    constexpr int G = 16 * ITEMS;                 // runs of 64 elements
-    static_assert(NB * G == SORT_THREADS, "one (digit, run) count per thread");
-    const int t = threadIdx.x;
-    const int lane = t & 63, w = t >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    if (bit_lo >= nbits) return;
-    int which = 0;
-    scratch[32 + t] = 0;
-    __syncthreads();
-    for (int bit = bit_lo; bit < nbits; bit += DB, which ^= 1) {
-        int* cnt = scratch + 32 + which * SORT_THREADS;              // [NB][G]
-        int* other = scratch + 32 + (which ^ 1) * SORT_THREADS;
-        const int sh = 32 + bit;
-        unsigned long long x[ITEMS], mk[ITEMS];
-        int dg[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            x[j] = buf[j * SORT_THREADS + t];
-            const int dgt = (int)((x[j] >> sh) & (unsigned long long)(NB - 1));
-            unsigned long long own = ~0ull;                          // lanes of this run with my digit
-#pragma unroll
-            for (int k = 0; k < DB; ++k) {
-                const unsigned long long mb = __ballot((dgt >> k) & 1);
-                own &= ((dgt >> k) & 1) ? mb : ~mb;
-            }
-            if ((own & lt) == 0ull) cnt[dgt * G + j * 16 + w] = __popcll(own);
-            dg[j] = dgt;
-            mk[j] = own;
-        }
-        __syncthreads();
-        const int v = cnt[t];
-        int tot_unused;
-        const int ex = block_excl_scan(v, scratch, &tot_unused);
-        cnt[t] = ex;
-        other[t] = 0;                                                // the next pass counts into a cleared array
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int rank = cnt[dg[j] * G + j * 16 + w] + __popcll(mk[j] & lt);
-            buf[rank] = x[j];
-        }
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ int key_bits(long long vocab) {
-    int nbits = 1;
-    const unsigned long long vmax = (unsigned long long)(vocab - 1);
-    while ((vmax >> nbits) != 0 && nbits < 32) ++nbits;
-    return nbits;
-}
-
-// ---- segmentation of the n sorted items in buf: heads of runs of equal keys, chunk heads every L sorted
-// positions; writes the plan arrays of field f.  Items are taken striped as in the radix passes, so every wave
-// holds 64 consecutive sorted positions: ballots give the heads before a lane inside its run of 64, one scan over
-// the 16*ITEMS run totals gives the heads before the run, and every plan array is written with consecutive
-// addresses per wave ------------------------------------------------------------------------------------------
-// `src` holds the field's sorted list (LDS or global), indexed by sorted position; the workgroup covers positions
-// pos0 .. pos0 + 1024*ITEMS.  prior / prior_pads: heads | chunk heads << 16 and padding entries before pos0;
-// the workgroup with `last` set writes the end marks and the counts.
-template <int ITEMS>
-__device__ __forceinline__ void segment_tail(const SortArgs& a, int f, const unsigned long long* src, int* scratch, int n,
-                                             int pos0 = 0, int prior = 0, int prior_pads = 0, bool last = true) {
-    constexpr int RUNS = 16 * ITEMS;
-    static_assert(RUNS <= SORT_THREADS, "one run total per thread");
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int* run_heads = scratch + 32;                // [RUNS] heads | chunk heads << 16
-    int* run_pads = run_heads + RUNS;             // [RUNS]
-    unsigned lo[ITEMS], key[ITEMS];
-    int st[ITEMS];                                // bit 0 head, bit 1 chunk head, bit 2 padding, bits 8.. / 16..: heads / chunk heads before the lane in its run
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int i = pos0 + j * SORT_THREADS + t;
-        const unsigned long long e = i < n ? src[i] : ~0ull;
-        lo[j] = (unsigned)(e & 0xFFFFFFFFull);
-        key[j] = (unsigned)(e >> 32);
-        const bool valid = i < n;
-        const bool pad = valid && key[j] == 0u;
-        const bool live = valid && !pad;
-        const bool head = live && (i == 0 || (unsigned)(src[i - 1] >> 32) != key[j]);
-        const bool chead = live && (head || (i % a.L == 0));
-        const unsigned long long hb = __ballot(head), cb = __ballot(chead), pb = __ballot(pad);
-        if (lane == 0) {
-            run_heads[j * 16 + w] = __popcll(hb) | (__popcll(cb) << 16);
-            run_pads[j * 16 + w] = __popcll(pb);
-        }
-        st[j] = (head ? 1 : 0) | (chead ? 2 : 0) | (pad ? 4 : 0) | (__popcll(hb & lt) << 8) | (__popcll(cb & lt) << 16);
-    }
-    __syncthreads();
-    const int rh = t < RUNS ? run_heads[t] : 0, rp = t < RUNS ? run_pads[t] : 0;
-    int tot, totpad;
-    const int ex = block_excl_scan(rh, scratch, &tot) + prior;
-    (void)block_excl_scan(rp, scratch, &totpad);
-    tot += prior;
-    totpad += prior_pads;
-    __syncthreads();
-    if (t < RUNS) run_heads[t] = ex;
-    __syncthreads();
-    const int n_seg = tot & 0xFFFF, n_chunk = tot >> 16;
-    int* sorted_src = a.sorted_src + (long long)f * a.cap;
-    int* entry_chunk = a.entry_chunk + (long long)f * a.cap;
-    int* entry_seg = a.entry_seg + (long long)f * a.cap;
-    int* chunk_start = a.chunk_start + (long long)f * (a.cap + 1);
-    int* seg_row = a.seg_row + (long long)f * a.cap;
-    int* seg_first_chunk = a.seg_first_chunk + (long long)f * (a.cap + 1);
-    const int roff = (int)a.row_offset[f];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int i = pos0 + j * SORT_THREADS + t;
-        if (i < n) {
-            const int base = run_heads[j * 16 + w];
-            const int seg = (base & 0xFFFF) + ((st[j] >> 8) & 0xFF);      // heads before this position
-            const int chk = (base >> 16) + ((st[j] >> 16) & 0xFF);        // chunk heads before this position
-            sorted_src[i] = (int)lo[j];
-            if (st[j] & 1) {
-                seg_row[seg] = roff + (int)key[j];
-                seg_first_chunk[seg] = chk;
-            }
-            if (st[j] & 2) chunk_start[chk] = i;
-            const bool pad = (st[j] & 4) != 0;
-            entry_chunk[i] = pad ? -1 : chk + ((st[j] >> 1) & 1) - 1;
-            entry_seg[i] = pad ? -1 : seg + (st[j] & 1) - 1;
-        }
-    }
-    if (t == 0 && last) {
-        chunk_start[n_chunk] = n;
-        seg_first_chunk[n_seg] = n_chunk;
-        int* c = a.counts + f * 4;
-        c[0] = n; c[1] = n_chunk; c[2] = n_seg; c[3] = totpad;
-    }
-}
-
-template <int ITEMS>
-__device__ __forceinline__ void field_sort_body(const SortArgs& a, int f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];   // [1024*ITEMS]
-    int* scratch = reinterpret_cast<int*>(buf + SORT_THREADS * ITEMS);         // [32] + 2 x [1024]
-    const int t = threadIdx.x;
-    constexpr int CAPB = SORT_THREADS * ITEMS;
-    const int nbits = key_bits(a.vocab[f]);
-    const int split_bit = radix_digit_bits<ITEMS>() * a.split_passes;
-    unsigned long long* spill = a.spill + (long long)f * a.cap;
-
-    int n = 0;
-    if (a.phase != 2) {
-        // ---- load the field's sub-lists into LDS in list order (position = order of arrival) ----
-        for (int s = 0; s < a.nsrc; ++s) {
-            const int cnt = a.sub_cnt[s * a.F + f];
-            const int off = a.sub_off[s * a.F + f];
-            const int pb = a.pay_base[s * a.F + f];
-            const long long V = a.vocab[f];
-            for (int j = t; j < cnt; j += SORT_THREADS) {
-                long long k = a.keys[off + j];
-                if (k < 0 || k >= V) k = 0;    // out-of-range was flagged by the forward; treat as padding
-                buf[n + j] = ((unsigned long long)(unsigned)k << 32) | (unsigned)(pb + j * a.pay_stride);
-            }
-            n += cnt;
-        }
-    } else {
-        for (int s = 0; s < a.nsrc; ++s) n += a.sub_cnt[s * a.F + f];
-        for (int j = t; j < n; j += SORT_THREADS) buf[j] = spill[j];
-    }
-    for (int j = n + t; j < CAPB; j += SORT_THREADS) buf[j] = ~0ull;   // sentinels sort last
-    __syncthreads();
-    if (a.phase == 1) {
-        radix_passes<ITEMS>(buf, scratch, min(nbits, split_bit));
-        for (int j = t; j < n; j += SORT_THREADS) spill[j] = buf[j];    // the sentinels stay behind the n items
-        return;
-    }
-    radix_passes<ITEMS>(buf, scratch, nbits, a.phase == 2 ? split_bit : 0);
-    segment_tail<ITEMS>(a, f, buf, scratch, n);
-}
 
 // ---- two-level form for one list per field (columnar batches) of more than 1024 entries -------------------
 // The single-workgroup sort keeps F of the 256 compute units busy and pays one pass per 2..4 key bits once a thread
@@ -449,7 +215,8 @@ __device__ __forceinline__ void tile_tail_body(const SortArgs& a, int f, int q, 
 
 template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void field_sort_kernel(SortArgs a) {
-    field_sort_body<ITEMS>(a, blockIdx.x);
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sort_buf[];
+    field_sort_body<ITEMS>(a, blockIdx.x, sort_buf);
 }
 
 template <int IT>
@@ -486,8 +253,9 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_gather_kernel(SortArgs
 // gather costs no time of its own.
 template <int ITEMS, int VEC>
 __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(SortArgs a, GatherArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sort_buf[];
     if ((int)blockIdx.x < a.F) {
-        field_sort_body<ITEMS>(a, blockIdx.x);
+        field_sort_body<ITEMS>(a, blockIdx.x, sort_buf);
         return;
     }
     gather_fused_body<VEC>(ga, ((int)blockIdx.x - a.F) * (SORT_THREADS / 64) + (threadIdx.x >> 6));
@@ -497,8 +265,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(SortArgs a, G
 // batch, the sort keeps F workgroups busy and the replay of skipped Adam steps runs on the workgroups behind them.
 template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void sort_catchup_kernel(SortArgs a, CatchArgs ca, int per_table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sort_buf[];
     if ((int)blockIdx.x < a.F) {
-        field_sort_body<ITEMS>(a, blockIdx.x);
+        field_sort_body<ITEMS>(a, blockIdx.x, sort_buf);
         return;
     }
     catchup_block<SORT_THREADS>(ca, (int)blockIdx.x - a.F, per_table);
@@ -915,6 +684,35 @@ __global__ __launch_bounds__(256) void sparse_dense_update_kernel(UpdateArgs a, 
     }
 }
 
+// sparse_dense_update_kernel with, in front of it, the replay of skipped Adam steps for the distinct rows of the NEXT
+// batch (its sorted plan; rowstate_body.h, catchup_seg_block): rows the update steps carry the stamp *step and are left
+// alone by the replay, every other row of the next batch is not touched by the update -- the two never meet on a row.
+template <int VEC>
+__global__ __launch_bounds__(256) void sparse_dense_update_ahead_kernel(UpdateArgs a, int gx, float* __restrict__ w,
+                                                                        const float* __restrict__ g, float* m, float* v,
+                                                                        long long n, int n_dense_blocks, SegCatchArgs sc,
+                                                                        int sx) {
+    const int nca = sc.F * sx;
+    int b = blockIdx.x;
+    if (b < nca) {
+        catchup_seg_block<VEC, 256>(sc, b / sx, b % sx);
+        return;
+    }
+    b -= nca;
+    const int nsp = a.F * gx;
+    if (b < nsp) {
+        sparse_update_body<VEC>(a, b / gx, b % gx);
+        return;
+    }
+    const float coef = a.scal ? a.scal[1] : 1.f;
+    const long long stride = (long long)n_dense_blocks * 256;
+    for (long long i = (long long)(b - nsp) * 256 + threadIdx.x; i < n; i += stride) {
+        float ww = w[i];
+        opt_update(a.opt, a.hyper, g[i] * coef, ww, m ? m + i : nullptr, v ? v + i : nullptr);
+        w[i] = ww;
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void scatter_rowgrad_kernel(UpdateArgs a) {
     // a.table = dense gradient [R, d] (pre-zeroed), a.table1 = dense 1-dim gradient [R]
@@ -1057,7 +855,6 @@ bool two_level_shape(int n, int nsrc, TwoLevelShape* s) {
 inline unsigned long long* plan_tiles(int* plan, int F, int cap) {
     return reinterpret_cast<unsigned long long*>(plan + (size_t)F * (6 * (size_t)cap + 2 + 4));
 }
-inline size_t sort_lds(int items) { return (size_t)SORT_THREADS * items * 8 + (32 + 2 * SORT_THREADS) * sizeof(int); }
 
 // launches 2 and 3 of the two-level sort
 int launch_rank_tail(const SortArgs& a, const TwoLevelShape& sh, unsigned long long* tiles64, hipStream_t stream) {
@@ -1538,6 +1335,49 @@ int rs_sparse_dense_update(const int* plan, int F, int cap, int d, int opt, cons
     else hipLaunchKernelGGL(sparse_dense_update_kernel<1>, grid, block, 0, stream, a, gx, dense_w, dense_g, dense_m, dense_v,
                             dense_n, ndb);
     RS_CHECK_LAUNCH("rs_sparse_dense_update");
+    return RS_OK;
+}
+
+// rs_sparse_dense_update (which gets no stamps to write) and, in the same launch, rs_adam_catchup_plan(mode 0) for
+// `next_plan`, the sorted plan (same F and cap) of the batch the NEXT step trains on: what that step would otherwise do
+// before its lookup happens here, beside the update, on rows the update does not touch.  The rows of `plan` must carry
+// the stamp *step (an earlier rs_adam_catchup_plan / this entry point promised them to this update).
+int rs_sparse_dense_update_ahead(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
+                                 float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
+                                 const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,
+                                 const float* scal, const int* next_plan, int* last, int* last1, const long long* step,
+                                 const float* bctab, int tab_n, int kmax, hipStream_t stream) {
+    RS_CHECK_ARG(plan && hyper && dense_w && dense_g && dense_n >= 0 && next_plan && step,
+                 "rs_sparse_dense_update_ahead: null argument");
+    RS_CHECK_ARG(opt == OPT_ADAM || opt == OPT_ADAMW, "rs_sparse_dense_update_ahead: optimizer %d has nothing to replay", opt);
+    RS_CHECK_ARG(!table || rowgrad, "rs_sparse_dense_update_ahead: table without rowgrad");
+    RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_dense_update_ahead: table1 without rowgrad1");
+    RS_CHECK_ARG((!table || (m && v)) && (!table1 || (m1 && v1)) && dense_m && dense_v,
+                 "rs_sparse_dense_update_ahead: Adam needs m and v");
+    RS_CHECK_ARG(kmax >= 0 && tab_n >= 0 && (tab_n == 0 || bctab), "rs_sparse_dense_update_ahead: bad replay table");
+    UpdateArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_dense_update_ahead: unsupported d=%d", d);
+    a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1; a.opt = opt; a.table = table; a.m = m; a.v = v;
+    a.table1 = table1; a.m1 = m1; a.v1 = v1; a.hyper = hyper; a.scal = scal;
+    a.last = nullptr; a.last1 = nullptr; a.step = step;
+    const PlanView nv = carve_plan(const_cast<int*>(next_plan), F, cap);
+    SegCatchArgs sc{};
+    const int nt = fill_seg_catchup(sc, nv.seg_row, nv.counts, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step,
+                                    hyper, bctab, tab_n, kmax, 0);
+    RS_CHECK_ARG(nt > 0, "rs_sparse_dense_update_ahead: no table, or a table without m / v / last, or a row width the kernels do not take (%d)", d);
+    // the replay kernel's lanes per row follow the first table it is given, as the update's do
+    const int vec_c = sc.t[0].d % 4 == 0 ? 4 : 1;
+    RS_CHECK_ARG(vec_c == VEC, "rs_sparse_dense_update_ahead: row width %d of the replayed table does not fit d=%d", sc.t[0].d, d);
+    const int gx = rs_cdiv(cap, 256 / a.C), sx = rs_cdiv(cap, seg_rows_per_block(sc.t[0].d, 256));
+    long long db = (dense_n + 255) / 256;
+    const int ndb = (int)(db > 2048 ? 2048 : (db < 1 ? 1 : db));
+    dim3 grid(F * sx + F * gx + ndb), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(sparse_dense_update_ahead_kernel<4>, grid, block, 0, stream, a, gx, dense_w, dense_g,
+                                     dense_m, dense_v, dense_n, ndb, sc, sx);
+    else hipLaunchKernelGGL(sparse_dense_update_ahead_kernel<1>, grid, block, 0, stream, a, gx, dense_w, dense_g, dense_m,
+                            dense_v, dense_n, ndb, sc, sx);
+    RS_CHECK_LAUNCH("rs_sparse_dense_update_ahead");
     return RS_OK;
 }
 

@@ -536,7 +536,7 @@ class DistributedTrainer(FusedTrainer):
                     rs=self.rs_shard, rs1=self.rs_shard1)
 
     # ---- HIP-graph segments between the collectives --------------------------------------------------
-    def _capture(self, idx, labels):
+    def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
         """Record one step reading `idx`/`labels` in place as graph segments + collectives; the training state is
         left as it was (the warm-up steps run for real -- collectives included, on every rank -- and are undone).
         use_graph="full": one HIP graph for the whole step with the RCCL collectives captured inside it (other
@@ -544,7 +544,7 @@ class DistributedTrainer(FusedTrainer):
         if self.use_graph == "full":
             self._capture_error_mode = "thread_local"
             return FusedTrainer._capture(self, idx, labels)
-        ent = {"idx": idx, "labels": labels}
+        ent = {"idx": idx, "labels": labels, "ahead_after": None}
         snap = [(t, t.clone()) for t in self._mutable_state()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())

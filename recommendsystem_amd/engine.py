@@ -151,6 +151,9 @@ class FusedTrainer:
         # every check_every steps -- a host synchronisation -- and by check() before tables are read as a whole
         self.check_every = 256
         self._unchecked = 0
+        # Work of the NEXT batch done inside a step (step_tensors(..., next_idx=...)): which tensor it was done for and
+        # which of the two plans holds its sort.  None: the next step does that work itself, in front of its lookup.
+        self._ahead = None
 
     # ------------------------------------------------------------------------------------------
     def _dense_params(self):
@@ -260,13 +263,40 @@ class FusedTrainer:
         self.hyper[0:1].fill_(self.lr)
         return self.lr
 
-    def plan(self, B: int) -> ops.SparsePlan:
-        if B not in self._plans:
+    def plan(self, B: int, slot: int = 0) -> ops.SparsePlan:
+        """Sort plan + reduction buffers for batches of B samples.  Two slots: while a step works with one, the sort of
+        the next batch may already be written into the other (step_tensors(..., next_idx=...))."""
+        key = (B, slot)
+        if key not in self._plans:
             p = ops.SparsePlan(self.layout, cap=B, d=self.d, with_lr=self.has_lr)
             n_extra = N_DENSE_PARTIALS * (1 + len(self.tables))
             p.partials = torch.zeros(p.n_partials + n_extra, dtype=torch.float32, device=self.device)
-            self._plans[B] = p
-        return self._plans[B]
+            self._plans[key] = p
+        return self._plans[key]
+
+    # ---- work of the next batch done inside a step -------------------------------------------------------------
+    def _ahead_supported(self, B: int) -> bool:
+        """The sort of the next batch can ride in a backward GEMM launch and its Adam catch-up beside the update."""
+        return (self._fuse_small and not self.overlap and not self.net_reg and self.mode == "sparse"
+                and B <= ops.group_sort_max_entries())
+
+    @staticmethod
+    def _tensor_key(t: torch.Tensor):
+        return (t.data_ptr(), t._version, tuple(t.shape))
+
+    def _ahead_slot_for(self, idx: torch.Tensor):
+        """Slot of the plan that already holds the sort (and catch-up) of `idx`, or None."""
+        a = self._ahead
+        if a is not None and a["key"] == self._tensor_key(idx):
+            return a["slot"]
+        return None
+
+    def _cancel_ahead(self):
+        """The batch announced with next_idx did not come: take back the promise its rows carry."""
+        a, self._ahead = self._ahead, None
+        if a is not None and a["marked"]:
+            with ops.use_workspace(self.ws):
+                self.plan(a["B"], a["slot"]).catchup_plan(*self._row_states(), mode=1)
 
     # ------------------------------------------------------------------------------------------
     def forward_parts(self, idx: torch.Tensor, defer_head: bool = False, sort_plan=None, mark_ahead: int = 0):
@@ -277,7 +307,9 @@ class FusedTrainer:
         B = idx.shape[1]
         ctx = {"idx": idx, "B": B}
         parts = []
-        if self.exact and sort_plan is not None and mark_ahead == 0:
+        if sort_plan == "done":
+            r = self._embed_forward(idx)          # sorted and caught up during the step before: the lookup alone
+        elif self.exact and sort_plan is not None and mark_ahead == 0:
             # the replay of skipped Adam steps must precede the lookup: it shares the sort's launch, the gather follows
             # (the sort is cut in two where it can be: its first passes here, the rest beside the gather)
             sp = sort_plan.split_passes_for(B)
@@ -367,12 +399,18 @@ class FusedTrainer:
     def _reduce_dense_grads(self):
         """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
 
-    def _embed_update(self, plan, with_dense=False):
+    def _embed_update(self, plan, with_dense=False, stamps=True, next_plan=None):
         te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
         kw = dict(table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
                   table1=t1["w"].view(-1) if t1 else None, m1=t1["m"].view(-1) if t1 and t1["m"] is not None else None,
                   v1=t1["v"].view(-1) if t1 and t1["v"] is not None else None,
                   rs=(te or {}).get("rs"), rs1=(t1 or {}).get("rs"))
+        if next_plan is not None and self.exact:
+            plan.update_with_dense_ahead(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m, self.flat_v,
+                                         next_plan, **kw)
+            return
+        if not stamps:
+            kw["rs"] = kw["rs1"] = None
         if with_dense:
             plan.update_with_dense(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m, self.flat_v, **kw)
         else:
@@ -411,22 +449,46 @@ class FusedTrainer:
         current stream.  Returns immediately; join with current_stream().wait_stream(side)."""
         return _Fork(side, ws)
 
-    def _step_impl(self, idx: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    def _step_impl(self, idx: torch.Tensor, labels: torch.Tensor, next_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = idx.shape[1]
-        plan = self.plan(B)
+        # Was this batch announced to the step before (next_idx)?  Then its sort and its Adam catch-up are done.
+        slot = self._ahead_slot_for(idx)
+        done_ahead = slot is not None
+        if not done_ahead:
+            self._cancel_ahead()
+            slot = 0
+        self._ahead = None
+        do_ahead = (next_idx is not None and self._ahead_supported(B) and tuple(next_idx.shape) == tuple(idx.shape)
+                    and next_idx.dtype == torch.int64 and next_idx.is_contiguous())
+        plan = self.plan(B, slot)
+        next_plan = self.plan(B, 1 - slot) if do_ahead else None
+        # exact Adam with work done ahead: a batch's rows are stamped "stepped" before its update (catchup_plan), and
+        # the update writes no stamps
+        promised = self.exact and (done_ahead or do_ahead)
         main = torch.cuda.current_stream()
         overlap = self.overlap == 1
         keep = []                    # intermediates read on side streams stay alive until the join
         # The index sort needs only the batch: it runs beside the forward pass.
-        fork_sort = bool(self.overlap) and self._sort_can_fork
+        fork_sort = bool(self.overlap) and self._sort_can_fork and not done_ahead
         if fork_sort:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
         head_fast = bool(self.blocks) and self._head_fast
         # single GPU, one stream: the sort shares the gather's launch (it keeps only F workgroups busy)
         sort_early = self._fuse_small and not fork_sort
-        # the update at the end of the step stamps the rows it steps, so the catch-up does not mark ahead
-        parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
+        if done_ahead:
+            parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan="done")
+        elif promised:
+            # first step of a run that announces its batches: sort, then replay + promise per distinct row, then look up
+            plan.sort_columnar(idx)
+            plan.catchup_plan(*self._row_states(), mode=0)
+            parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan="done")
+        else:
+            # the update at the end of the step stamps the rows it steps, so the catch-up does not mark ahead
+            parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
+        sorted_already = fork_sort or sort_early or done_ahead or promised
+        ahead_sort_pending = do_ahead        # the next batch's sort still has to be issued
+        ahead_sort_half = False              # ... its first half has been
         lastb = self.blocks[-1] if self.blocks else None
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
         csp = ops.ColsumParts(ops.default_workspace(self.device)) if self.blocks else None
@@ -534,7 +596,15 @@ class FusedTrainer:
                                       mul_act=prev._act if fuse_prev else 0, colsum_part=csp if fuse_prev else None,
                                       dropout=mask_key)
                     if grp is not None:
-                        grp.launch()
+                        if ahead_sort_pending and self.group_gemms == 3 and i <= 1:
+                            # The sort of the next batch rides beside the two longest backward launches, half of it in
+                            # each (beside GEMM workgroups a sort workgroup takes several times as long as alone).
+                            phase = (2 if ahead_sort_half else 0) if i == 0 else 1
+                            grp.launch(sort=(next_plan, next_idx, phase))
+                            ahead_sort_half = phase == 1
+                            ahead_sort_pending = phase == 1
+                        else:
+                            grp.launch()
                     db_done = fuse_prev
                 else:
                     r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
@@ -567,6 +637,12 @@ class FusedTrainer:
 
         if fork_sort:
             main.wait_stream(self.side_sort)
+        if ahead_sort_pending:
+            # no GEMM launch to ride in (or none for the second half): a launch of its own
+            if ahead_sort_half:
+                next_plan._sort_in_group(None, 0, next_idx, 2)
+            else:
+                next_plan.sort_columnar(next_idx)
         # ---- embedding backward: segment reduce of the sorted batch -----------------------------
         P = plan.partials
         n_sp = plan.n_partials
@@ -575,13 +651,13 @@ class FusedTrainer:
         # come out of the embedding reduction's second launch and the two optimizer steps share one launch
         fuse = self._fuse_small and not overlap and not self.net_reg and self.mode == "sparse"
         if fuse:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, dense_partials=dense_p,
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=sorted_already, dense_partials=dense_p,
                                  colsum=pending_colsum, splitk=pending_splitk)
         elif pending_colsum is not None or pending_splitk is not None:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early, colsum=pending_colsum,
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=sorted_already, colsum=pending_colsum,
                                  splitk=pending_splitk)
         else:
-            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=fork_sort or sort_early)
+            self._embed_backward(plan, idx, gout, dz, ctx, sorted_already=sorted_already)
 
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
@@ -611,11 +687,15 @@ class FusedTrainer:
 
         # ---- optimizer --------------------------------------------------------------------------
         both = fuse or (self._update_shares_launch and self.mode == "sparse")     # dense and touched-row steps in one launch
-        if both:
+        if promised:
+            # the rows of this batch carry their stamp already; beside the update, the rows of the next batch are
+            # brought up to date and promised to the next update
+            self._embed_update(plan, with_dense=True, stamps=False, next_plan=next_plan)
+        elif both:
             self._embed_update(plan, with_dense=True)
         else:
             ops.dense_update(self.flat_w, self.flat_g, self.flat_m, self.flat_v, self.opt, self.hyper, self.scal)
-        if both:
+        if both or promised:
             pass
         elif self.mode == "sparse":
             self._embed_update(plan)
@@ -623,6 +703,8 @@ class FusedTrainer:
             for t in self.tables:
                 ops.dense_update(t["w"].view(-1), t["g"].view(-1), t["m"].view(-1) if t["m"] is not None else None,
                                  t["v"].view(-1) if t["v"] is not None else None, self.opt, self.hyper, self.scal)
+        if do_ahead:
+            self._ahead = {"key": self._tensor_key(next_idx), "slot": 1 - slot, "B": B, "marked": self.exact}
         self.last = {"dz": dz, "parts": parts}
         del keep
         return loss
@@ -651,29 +733,40 @@ class FusedTrainer:
         return loss
 
     # ------------------------------------------------------------------------------------------
-    def step_tensors(self, idx: torch.Tensor, labels: torch.Tensor, resident: bool = False) -> torch.Tensor:
+    def step_tensors(self, idx: torch.Tensor, labels: torch.Tensor, resident: bool = False,
+                     next_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One training step on device-resident inputs: idx [F, B] int64, labels [B] int64/float32.
 
         With use_graph, the step is replayed from a HIP graph.  resident=False copies the batch into
         the graph's static input buffers first (what a host feeder does with its one H2D copy per
         step).  resident=True promises that these exact tensors stay alive and are re-used (a ring of
         pre-staged batches): one graph is captured per distinct (idx, labels) buffer pair and
-        replayed without any copy."""
+        replayed without any copy.
+
+        next_idx announces the index matrix of the NEXT call (the same tensor object, contents unchanged until then;
+        a feeder that stages batches ahead knows it).  Everything that depends on nothing but the batch -- the index
+        sort of the sparse backward and, with exact Adam, the replay of the skipped steps of its rows -- is then done
+        inside this step, beside its GEMMs and its update, and the next step starts with the lookup.  A promise that
+        is not kept costs one small launch (the rows' stamps are taken back); results do not depend on next_idx."""
         self._check_tables()
         self._unchecked += 1
         if self.check_every and self._unchecked >= self.check_every:
             self.check()
+        if self._ahead is not None and self._ahead_slot_for(idx) is None:
+            self._cancel_ahead()
         if not self.use_graph:
             with ops.use_workspace(self.ws):
-                return self._step_impl(idx, labels)
+                return self._step_impl(idx, labels, next_idx)
         if resident:
-            key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
+            key = self._graph_key(idx, labels, next_idx, self._ahead)
             ent = self._graphs.get(key)
             if ent is None:
-                ent = self._capture(idx, labels)
+                ent = self._capture(idx, labels, next_idx, self._ahead)
                 self._graphs[key] = ent
             ent["graph"].replay()
+            self._ahead = dict(ent["ahead_after"]) if ent["ahead_after"] else None
             return ent["loss"]
+        self._cancel_ahead()
         key = ("static", tuple(idx.shape), labels.dtype)
         ent = self._graphs.get(key)
         if ent is None:
@@ -684,38 +777,64 @@ class FusedTrainer:
         ent["graph"].replay()
         return ent["loss"]
 
-    def prepare(self, idx: torch.Tensor, labels: torch.Tensor):
-        """use_graph: capture the step of a resident batch (step_tensors(idx, labels, resident=True)) now, without
-        stepping; the training state is left as it was."""
+    def _graph_key(self, idx, labels, next_idx, entry):
+        """A captured step depends on its buffers, on the buffer it prepares the next step for, and on whether (and in
+        which plan) its own batch was prepared by the step before."""
+        use_next = next_idx is not None and self._ahead_supported(idx.shape[1])
+        return (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype,
+                next_idx.data_ptr() if use_next else None, entry["slot"] if entry else None)
+
+    def prepare(self, idx: torch.Tensor, labels: torch.Tensor, next_idx: Optional[torch.Tensor] = None,
+                ahead_slot: Optional[int] = None):
+        """use_graph: capture the step of a resident batch (step_tensors(idx, labels, resident=True, next_idx=next_idx))
+        now, without stepping; the training state is left as it was.  ahead_slot (0 / 1): capture the form the step
+        takes when the step before it announced this batch and sorted it into that plan slot (slots alternate from
+        step to step, starting with 1 for the step after an unannounced one)."""
         if not self.use_graph:
             return
-        key = (idx.data_ptr(), labels.data_ptr(), tuple(idx.shape), labels.dtype)
+        entry = None
+        if ahead_slot is not None and self._ahead_supported(idx.shape[1]):
+            entry = {"key": self._tensor_key(idx), "slot": int(ahead_slot), "B": idx.shape[1], "marked": self.exact}
+        key = self._graph_key(idx, labels, next_idx, entry)
         if key not in self._graphs:
-            self._graphs[key] = self._capture(idx, labels)
+            saved = self._ahead
+            self._graphs[key] = self._capture(idx, labels, next_idx, entry, run_prologue=entry is not None)
+            self._ahead = saved
 
-    def _capture(self, idx, labels):
-        """Capture one step reading `idx`/`labels` in place; the model state is left untouched."""
-        ent = {"idx": idx, "labels": labels}
+    def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
+        """Capture one step reading `idx`/`labels` in place; the model state is left untouched.  entry: the record of
+        work done ahead (self._ahead) the step starts from; run_prologue: that work was not really done -- do it for
+        the warm-up steps (it is undone with everything else)."""
+        ent = {"idx": idx, "labels": labels, "next_idx": next_idx}
         # snapshot everything a step mutates, warm up (first launches set kernel attributes), restore
         snap = [(t, t.clone()) for t in self._mutable_state()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), ops.use_workspace(self.ws):
+            if run_prologue:
+                p = self.plan(entry["B"], entry["slot"])
+                p.sort_columnar(idx)
+                if entry["marked"]:
+                    p.catchup_plan(*self._row_states(), mode=0)
             for _ in range(2):
-                self._step_impl(idx, labels)
+                self._ahead = dict(entry) if entry else None
+                self._step_impl(idx, labels, next_idx)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for t, c in snap:
             t.copy_(c)
+        self._ahead = dict(entry) if entry else None
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=self._capture_error_mode), \
                 ops.use_workspace(self.ws):
-            ent["loss"] = self._step_impl(idx, labels)
+            ent["loss"] = self._step_impl(idx, labels, next_idx)
+        ent["ahead_after"] = self._ahead
         if self._graph_pool is None:
             self._graph_pool = g.pool()
         torch.cuda.synchronize()
         for t, c in snap:       # capture does not execute, but keep the state exactly as before
             t.copy_(c)
+        self._ahead = dict(entry) if entry else None
         ent["graph"] = g
         return ent
 

@@ -267,6 +267,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_mc=False, b_nc=False, bias=None,
 GROUP_STAGES = int(os.environ.get("RS_GROUP_GEMMS", "3"))
 
 
+def group_sort_max_entries() -> int:
+    """Largest batch whose index sort can ride in a grouped GEMM launch (GemmGroup.launch(sort=...))."""
+    return _lib.lib().rs_group_sort_max_entries()
+
+
 # Radix passes of the one-workgroup index sort that run in the catch-up's launch when the sort is cut in two (the rest
 # runs in the gather's launch); 0 = the whole sort beside the catch-up.  Measured at B=4096, 39 fields (rocprofv3): whole
 # sort beside the catch-up 27.7 us + gather 9.2 us; 3 passes 19.2 + 17.1; every pass of the 20-bit fields first and only
@@ -349,12 +354,22 @@ class GemmGroup:
         self._keep += [a, b, out, bias, mulsrc]
         return out
 
-    def launch(self):
+    def launch(self, sort=None):
+        """sort = (plan, idx, phase): the launch also sorts the columnar batch idx [F, B] into `plan` (SparsePlan.
+        sort_columnar of the NEXT batch riding beside these products; needs 3 stages and B <= group_sort_max_entries()).
+        phase 0: the whole sort; 1 / 2: its two halves, in two launches (plan.ride_split_passes(B) passes first)."""
         descs, self._descs, self._keep = self._descs, [], []
         for i in range(0, len(descs), 4):
             grp = descs[i:i + 4]
             arr = (_lib.GemmDesc * len(grp))(*grp)
-            call("rs_gemm_f32_group", arr, len(grp), int(self.stages), stream())
+            if sort is not None and i + 4 >= len(descs) and self.stages == 3 and sort[1].shape[1] <= group_sort_max_entries():
+                plan, idx, phase = sort
+                plan._sort_in_group(arr, len(grp), idx, phase)
+                sort = None
+            else:
+                call("rs_gemm_f32_group", arr, len(grp), int(self.stages), stream())
+        if sort is not None:                     # nothing was collected: the sort (or this half of it) in a launch of its own
+            sort[0]._sort_in_group(None, 0, sort[1], sort[2])
 
 
 class SplitKParts:
@@ -744,6 +759,53 @@ class SparsePlan:
         off, cnt, base = self.columnar_lists(B)
         call("rs_sparse_bwd_sort", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.F, 1, self.F, self.cap, B,
              self.CHUNK, ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan), stream())
+
+    @staticmethod
+    def ride_split_passes(B: int) -> int:
+        """Radix passes in the first half of a sort that rides in two GEMM launches (4 key bits per pass above 1024
+        entries per field, 6 below): three of the five passes of a 20-bit key, two of the four of an 18..24-bit one."""
+        return 3 if B > 1024 else 2
+
+    def _sort_in_group(self, descs, count: int, idx: torch.Tensor, phase: int = 0):
+        Fn, B = idx.shape
+        _chk(idx, torch.int64, "idx", (self.F, B))
+        if B > self.cap:
+            raise RSError(f"sparse backward: batch {B} exceeds plan capacity {self.cap}")
+        off, cnt, base = self.columnar_lists(B)
+        call("rs_gemm_f32_group_sort", descs, int(count), ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK,
+             ptr(self.layout.vocab_t), ptr(self.layout.row_offset_t), ptr(self.plan), B, Fn, int(phase),
+             self.ride_split_passes(B) if phase else 0, stream())
+
+    def catchup_plan(self, main, one, mode: int = 0):
+        """Exact Adam on touched rows for the DISTINCT rows of the batch this plan has sorted (main / one: the RowAdam
+        states of the [R, d] and the 1-dim table).  mode 0: rows behind the step count are replayed up to it and every
+        row of the plan is stamped step + 1 -- promised to the update that steps it next, which must then write no stamps
+        itself; mode 1 takes that promise back."""
+        ref = main or one
+        if ref is None:
+            return
+        for st in (main, one):
+            if st is not None and st.rows != self.layout.total_rows:
+                raise RSError("catchup_plan: table and field layout disagree on the number of rows")
+        g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
+        call("rs_adam_catchup_plan", ptr(self.plan), self.F, self.cap, main.d if main else 1, g(main, "w"), g(main, "m"),
+             g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt],
+             ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, int(mode), stream())
+
+    def update_with_dense_ahead(self, opt: str, hyper, scal, dense_w, dense_g, dense_m, dense_v, next_plan: "SparsePlan",
+                                table=None, m=None, v=None, table1=None, m1=None, v1=None, rs=None, rs1=None):
+        """update_with_dense (no stamps written: the rows of this plan were promised to this update by catchup_plan) and
+        next_plan.catchup_plan(rs, rs1) in one launch."""
+        _chk(dense_w, torch.float32, "dense_w")
+        _chk(dense_g, torch.float32, "dense_g", dense_w.shape)
+        ref = rs or rs1
+        if ref is None or next_plan.cap != self.cap or next_plan.F != self.F:
+            raise RSError("update_with_dense_ahead: needs the tables' RowAdam states and a next plan of the same shape")
+        call("rs_sparse_dense_update_ahead", ptr(self.plan), self.F, self.cap, self.d, OPT_CODES[opt], ptr(self.rowgrad),
+             ptr(self.rowgrad1), ptr(table), ptr(m), ptr(v), ptr(table1), ptr(m1), ptr(v1), ptr(dense_w), ptr(dense_g),
+             ptr(dense_m), ptr(dense_v), dense_w.numel(), ptr(hyper), ptr(scal), ptr(next_plan.plan),
+             ptr(rs.last) if rs is not None else None, ptr(rs1.last) if rs1 is not None else None, ptr(ref.step),
+             ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, stream())
 
     def sort_and_gather(self, idx: torch.Tensor, table, table1, bias, want_emb=True, want_sum=False, want_lr=False,
                         want_fm=False, resume_passes: int = 0):
