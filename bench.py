@@ -72,10 +72,13 @@ def parse():
     p.add_argument("--force-dist", type=int, default=0,
                    help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
                         "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
-    p.add_argument("--dist-graph", type=int, default=0,
-                   help="N>1: 0 = eager (default); 1 = HIP-graph segments between the collectives (measured slower than "
-                        "eager on one rank); 2 = one HIP graph with the RCCL collectives captured inside (measured on one "
-                        "rank only)")
+    p.add_argument("--dist-graph", type=int, default=1,
+                   help="N>1: 1 (default) = the whole step, RCCL collectives included, is one HIP graph per resident batch; "
+                        "0 = issued eagerly (host-bound: about thirty entry-point calls and five collectives per step)")
+    p.add_argument("--overlap-comm", type=int, default=-1,
+                   help="sharded tables: all-reduce of the dense gradient on a second stream and communicator beside the "
+                        "gradient all-to-all and the owner-side reduction (0: everything on one stream; default: with more "
+                        "than one rank)")
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
@@ -252,7 +255,9 @@ def main():
     if use_dist and fused_kind:
         from recommendsystem_amd.dist import DistributedTrainer, ReplicatedTablesTrainer
         cls = ReplicatedTablesTrainer if args.tables == "replicated" else DistributedTrainer
-        eng = cls(model, mode=args.mode, use_graph={0: False, 1: True, 2: "full"}[args.dist_graph], stage_cpu=rehearse)
+        kw = {"overlap_comm": None if args.overlap_comm < 0 else bool(args.overlap_comm)} if cls is DistributedTrainer else {}
+        # gloo with host staging (the one-GPU rehearsal) cannot be captured
+        eng = cls(model, mode=args.mode, use_graph=bool(args.dist_graph) and not rehearse, stage_cpu=rehearse, **kw)
     elif use_dist:
         from recommendsystem_amd.dist import DistributedSparseTrainer
         eng = DistributedSparseTrainer(model, stage_cpu=rehearse)
@@ -280,19 +285,22 @@ def main():
     def announce(i):
         return {"next_idx": idx_dev[(i + 1) % nb]} if use_next else {}
 
-    if eng.use_graph and hasattr(eng, "prepare"):
+    # Several GPUs: ONE graph (RCCL collectives inside), every batch copied into its input buffers first -- what a
+    # feeder's one host-to-device copy per step does.
+    resident = not use_dist
+    if eng.use_graph and hasattr(eng, "prepare") and resident:
         for i in range(args.warmup + args.steps):
             kw = dict(announce(i), ahead_slot=(i % 2) if i > 0 else None) if use_next else {}
             eng.prepare(idx_dev[i % nb], lab_dev[i % nb], **kw)
     for i in range(args.warmup):
-        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True, **announce(i))
+        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=resident, **announce(i))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
 
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True, **announce(i))
+        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=resident, **announce(i))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

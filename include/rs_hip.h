@@ -355,12 +355,14 @@ int rs_sort_gather(const int64_t* idx, const int* sub_off, const int* sub_cnt, c
                    int F, int d, int* err_flag, int resume_passes, rs_stream_t stream);
 /* Row gradient of every touched row = sum over its entries r (sample b = r / Fdiv) of
  *   gout[r,:] + dfm[b]*(S[b,:] - emb[r,:])      and, for the 1-dim tables, g1src[r] + dlr[b]
- * (each term optional).  Also writes rs_sparse_bwd_num_partials(F,cap,d) partial sums of ||g||^2. */
+ * (each term optional).  Also writes rs_sparse_bwd_num_partials(F,cap,d) partial sums of ||g||^2.  ld_gout / ld_g1:
+ * floats between consecutive rows of gout / values of g1src (0: packed, d and 1) -- the owner side of the row-sharded
+ * exchange receives both in one buffer, the 1-dim gradient in a spare column behind the d-wide one. */
 int rs_sparse_bwd_num_partials(int F, int cap, int d);
 int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                          const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                          float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
-                         rs_stream_t stream);
+                         int ld_gout, int ld_g1, rs_stream_t stream);
 /* rs_sparse_bwd_reduce that also writes, from extra workgroups of its second launch, n_dense_partials
  * sum-of-squares partials of a dense buffer (the flat gradient of the dense parameters): both are pieces of the one
  * global norm of clip_grad_norm_ (BaseModel.py:148).  cs_*: up to 8 column-sum finishes (the arguments of
@@ -374,7 +376,8 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
                                float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
-                               const long long* sk_total, const int* sk_splitk, int sk_count, rs_stream_t stream);
+                               const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                               rs_stream_t stream);
 /* The same reduction for rows of W floats (W % 4 == 0, W <= 1024; field-aware FFM rows on the row-sharded path):
  * rowgrad[f, s, :] = sum of gout[sorted_src[q], :] over the entries of segment s, in ascending order; chunk_part
  * [F, cap, W] is scratch; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.  The plan's window L
@@ -478,20 +481,32 @@ int rs_sparse_dense_update_ahead(const int* plan, int F, int cap, int d, int opt
  * union of all ranks' batches).  Row i of a field lives on rank i % N at local index i / N + 1. ---- */
 /* Buckets: (owner o, field f) holds up to capf[f] distinct keys (device int32 [F]; a field with few rows needs no more
  * than its rows per owner); boff[f] = capf[0] + .. + capf[f-1], S = boff[F].  Key buffers are int64 [N, S + F] with
- * bucket (o, f) at o*(S+F) + boff[f] + f (count slot, then the keys); row and gradient buffers are [N, S, d] with row r
- * of bucket (o, f) at position o*S + boff[f] + r, which is also what route[f][u] holds for the u-th distinct key of
- * field f (-1: the key did not fit, *overflow_flag is set). */
+ * bucket (o, f) at o*(S+F) + boff[f] + f (count slot, then the keys); row and gradient buffers hold ld >= d floats per
+ * position, row r of bucket (o, f) at position o*S + boff[f] + r, which is also what route[f][u] holds for the u-th
+ * distinct key of field f (-1: the key did not fit, *overflow_flag is set).  With ld > d the value (or gradient) of the
+ * 1-dim LR table travels in a spare column of the same buffer: one all-to-all each way instead of two.
+ * rs_shard_counts: the owner's sub-list lengths from the count slots of the received buckets and, in the same launch,
+ * slot_map (int32 [F, B], may be NULL): per entry (f, b) of the requester's batch (its sorted `plan` of capacity cap and
+ * `route`) the position of its key's row, N*S -- a row of zeros the caller keeps behind the received rows -- for
+ * padding entries and lost keys; Fdiv: sample of gradient row r = r / Fdiv. */
 int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, int N, const int* capf, const int* boff,
                    int S, long long* send_idx, int* route, int* overflow_flag, rs_stream_t stream);
 int rs_shard_gather(const long long* recv_idx, const int64_t* local_row_offset, const int64_t* local_vocab, int N,
                     int F, const int* capf, const int* boff, int S, int cap_max, int d, const float* table,
-                    const float* table1, float* rows, float* rows1, int* err_flag, rs_stream_t stream);
+                    const float* table1, float* rows, float* rows1, int ld, int ld1, int* err_flag, rs_stream_t stream);
+/* The requester's lookup in the received rows: rs_gather_lr_fm_fwd (Layers.py:137-160, :107-109, FM.py:27-30; same
+ * outputs, same arithmetic and summation order) with entry (f, b) reading position slot_map[f*B + b] of `rows` (ld
+ * floats per position) and of `rows1` (the 1-dim values, ld1 floats apart) instead of a table row. */
+int rs_shard_lookup(const int* slot_map, const float* rows, int ld, const float* rows1, int ld1, const float* bias,
+                    float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B, int F, int d,
+                    rs_stream_t stream);
+/* The plain expansion (every entry copies the row of its distinct key), for rows wider than rs_shard_lookup takes. */
 int rs_shard_expand(const int* plan, const int* route, int F, int cap, int d, const float* rows,
                     const float* rows1, float* emb, float* lr1, rs_stream_t stream);
 int rs_shard_pack(const int* plan, const int* route, int F, int cap, int d, const float* rowgrad,
-                  const float* rowgrad1, float* grads, float* grads1, rs_stream_t stream);
+                  const float* rowgrad1, float* grads, float* grads1, int ld, int ld1, rs_stream_t stream);
 int rs_shard_counts(const long long* recv_idx, int N, int F, const int* capf, const int* boff, int S, int* sub_cnt,
-                    rs_stream_t stream);
+                    const int* plan, const int* route, int cap, int* slot_map, int B, int Fdiv, rs_stream_t stream);
 
 #ifdef __cplusplus
 }

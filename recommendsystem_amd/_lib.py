@@ -66,11 +66,11 @@ _SIGS = {
     "rs_sort_gather": [c_i64p, c_i32p, c_i32p, c_i32p, I, I, c_i64p, c_i64p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p,
                        c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, I, c_stream],
     "rs_sparse_bwd_reduce": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
-                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
+                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, c_stream],
     "rs_sparse_bwd_reduce_sumsq": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, I,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, c_stream],
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, I, I, c_stream],
     "rs_sparse_dense_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_i32p, c_i32p, c_i64p, c_stream],
     "rs_sparse_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
@@ -119,11 +119,12 @@ _SIGS = {
     "rs_loss_add_reg": [c_f32p, c_f32p, c_i32p, c_f32p, I, c_stream],
     # shard.hip
     "rs_shard_route": [c_i32p, I, I, c_i64p, I, c_i32p, c_i32p, I, c_i64p, c_i32p, c_i32p, c_stream],
-    "rs_shard_gather": [c_i64p, c_i64p, c_i64p, I, I, c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p,
-                        c_stream],
+    "rs_shard_gather": [c_i64p, c_i64p, c_i64p, I, I, c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, I, I,
+                        c_i32p, c_stream],
+    "rs_shard_lookup": [c_i32p, c_f32p, I, c_f32p, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_stream],
     "rs_shard_expand": [c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
-    "rs_shard_pack": [c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
-    "rs_shard_counts": [c_i64p, I, I, c_i32p, c_i32p, I, c_i32p, c_stream],
+    "rs_shard_pack": [c_i32p, c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, I, I, c_stream],
+    "rs_shard_counts": [c_i64p, I, I, c_i32p, c_i32p, I, c_i32p, c_i32p, c_i32p, I, c_i32p, I, I, c_stream],
     # interact.hip
     "rs_fm_fwd": [c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_fm_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_stream],

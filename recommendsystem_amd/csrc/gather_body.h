@@ -19,6 +19,11 @@ struct GatherArgs {
     float* fm_out;              // [B]       or null : 0.5*sum_k(S_k^2 - sum_f e_fk^2)
     int* err_flag;              // or null; set to 1 when an index is outside [0, vocab)
     int B, F, d, G, C;
+    // SLOTS form (the requester side of the row-sharded exchange): the row of entry (f, b) is slots[f*B + b] of a
+    // buffer of received rows instead of row_offset[f] + idx[f, b] of a table; `table` then points at that buffer with
+    // ld floats between rows and `table1` at its 1-dim column with ld1 floats between rows.
+    const int* slots;
+    int ld, ld1;
 };
 
 template <int VEC> struct VecT;
@@ -46,7 +51,7 @@ __device__ __forceinline__ void vstore(float* p, const float (&v)[VEC]) {
 constexpr int U = 8;  // fields in flight per lane
 
 // `wave`: index of this wave among all gather waves of the launch.
-template <int VEC>
+template <int VEC, bool SLOTS = false>
 __device__ __forceinline__ void gather_fused_body(const GatherArgs& a, int wave) {
     const int lane = threadIdx.x & 63;
     const int lps = a.G * a.C;            // lanes per sample
@@ -74,9 +79,13 @@ __device__ __forceinline__ void gather_fused_body(const GatherArgs& a, int wave)
             const int f = (i0 + u) * a.G + g;
             row[u] = -1;
             if (active && (i0 + u) < iters && f < a.F) {
-                long long ix = a.idx[(long long)f * a.B + b];
-                if (ix < 0 || ix >= a.vocab[f]) { bad = true; ix = 0; }
-                row[u] = a.row_offset[f] + ix;
+                if constexpr (SLOTS) {
+                    row[u] = a.slots[(long long)f * a.B + b];
+                } else {
+                    long long ix = a.idx[(long long)f * a.B + b];
+                    if (ix < 0 || ix >= a.vocab[f]) { bad = true; ix = 0; }
+                    row[u] = a.row_offset[f] + ix;
+                }
             }
         }
         float v[U][VEC];
@@ -87,8 +96,13 @@ __device__ __forceinline__ void gather_fused_body(const GatherArgs& a, int wave)
             for (int e = 0; e < VEC; ++e) v[u][e] = 0.f;
             w1[u] = 0.f;
             if (row[u] >= 0) {
-                if (a.table) vload<VEC>(a.table + row[u] * d + c * VEC, v[u]);
-                if (a.table1 && c == 0) w1[u] = a.table1[row[u]];
+                if constexpr (SLOTS) {
+                    if (a.table) vload<VEC>(a.table + row[u] * a.ld + c * VEC, v[u]);
+                    if (a.table1 && c == 0) w1[u] = a.table1[row[u] * a.ld1];
+                } else {
+                    if (a.table) vload<VEC>(a.table + row[u] * d + c * VEC, v[u]);
+                    if (a.table1 && c == 0) w1[u] = a.table1[row[u]];
+                }
             }
         }
 #pragma unroll

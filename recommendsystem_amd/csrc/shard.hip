@@ -9,7 +9,10 @@
 //   (all-to-all of send_idx)
 //   owner      shard_gather_kernel rows for every received local index -> rows[s][f][j][:], rows1[s][f][j]
 //   (all-to-all of rows, rows1)
-//   requester  shard_expand_kernel every batch entry copies the row of its distinct key -> emb[B,F,d], lr1[B,F]
+//   requester  shard_lookup_kernel the fused gather of the single-GPU path (gather_body.h) over the received rows:
+//                                  entry (f, b) reads the row of its distinct key through slot_map[f][b] (written by
+//                                  route_kernel) -> emb[B,F,d], sum over fields, FM term, LR sum, as K1 leaves them
+//              shard_expand_kernel the plain copy for rows wider than the fused gather takes (field-aware FFM rows)
 //   ... forward / backward of the dense part, local segmented reduce to one gradient per distinct key ...
 //   requester  shard_pack_kernel   distinct-key gradients into the same bucket positions
 //   (all-to-all of grads, grads1)
@@ -20,9 +23,13 @@
 // is what keeps the all-to-alls small -- and a bucket overflow sets *overflow_flag (checked by the caller outside the
 // step).  With boff[f] = capf[0] + .. + capf[f-1] and S = boff[F]:
 //   key buffers   [N, S + F] int64: bucket (o, f) starts at o*(S+F) + boff[f] + f (count slot first)
-//   row buffers   [N, S, d]:        row r of bucket (o, f) is at position o*S + boff[f] + r
+//   row buffers   [N, S, ld]:       row r of bucket (o, f) is at position o*S + boff[f] + r; ld >= d floats per position,
+//                                   so that the value of the 1-dim (LR) table can travel in a spare column of the same
+//                                   buffer (one all-to-all each way instead of two); position N*S is a row of zeros
+//                                   that padding entries and keys that did not fit their bucket are pointed at
 #include "common.h"
 #include "plan.h"
+#include "gather_body.h"
 
 namespace {
 
@@ -102,6 +109,18 @@ __global__ __launch_bounds__(RT_THREADS) void route_kernel(const int* __restrict
     }
 }
 
+// Requester: every entry (f, b) of the sorted batch -> the position of its key's row among the received rows (the zero
+// row at zero_slot for padding entries and keys that did not fit their bucket).  Entry i of field f in key order.
+__device__ __forceinline__ void slot_map_entry(const int* __restrict__ sorted_src, const int* __restrict__ entry_seg,
+                                               const int* __restrict__ counts, const int* __restrict__ route, int cap,
+                                               int zero_slot, int* __restrict__ slot_map, int B, int Fdiv, int f, int i) {
+    if (i >= counts[f * 4 + 0]) return;
+    const int u = entry_seg[(long long)f * cap + i];
+    int pos = u >= 0 ? route[(long long)f * cap + u] : -1;
+    if (pos < 0) pos = zero_slot;
+    slot_map[(long long)f * B + sorted_src[(long long)f * cap + i] / Fdiv] = pos;
+}
+
 // Owner side: rows for the received local indices.  grid (ceil(max capf / groups_per_block), N*F).
 template <int VEC>
 __global__ __launch_bounds__(256) void shard_gather_kernel(const long long* __restrict__ recv_idx,
@@ -110,7 +129,8 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(const long long* __re
                                                            const int* __restrict__ capf, const int* __restrict__ boff,
                                                            int S, int d, int C, const float* __restrict__ table,
                                                            const float* __restrict__ table1, float* __restrict__ rows,
-                                                           float* __restrict__ rows1, int* __restrict__ err_flag) {
+                                                           float* __restrict__ rows1, int ld, int ld1,
+                                                           int* __restrict__ err_flag) {
     const int sf = blockIdx.y;                 // s*F + f
     const int src = sf / F, f = sf - src * F;
     const int grp = threadIdx.x / C, cc = threadIdx.x - grp * C;
@@ -127,12 +147,18 @@ __global__ __launch_bounds__(256) void shard_gather_kernel(const long long* __re
     const long long o = (long long)src * S + bo + j;
     if (table) {
         if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(rows + o * d + cc * 4) = *reinterpret_cast<const float4*>(table + row * d + cc * 4);
+            *reinterpret_cast<float4*>(rows + o * ld + cc * 4) = *reinterpret_cast<const float4*>(table + row * d + cc * 4);
         } else {
-            rows[o * d + cc] = table[row * d + cc];
+            rows[o * ld + cc] = table[row * d + cc];
         }
     }
-    if (cc == 0 && table1) rows1[o] = table1[row];
+    if (cc == 0 && table1) rows1[o * ld1] = table1[row];
+}
+
+// Requester side, fused: K1 (gather_body.h) over the received rows, one slot per entry.
+template <int VEC>
+__global__ __launch_bounds__(256) void shard_lookup_kernel(GatherArgs a) {
+    gather_fused_body<VEC, true>(a, (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6));
 }
 
 // Requester side: emb[src, :] = rows[route[f][entry_seg]] for every sorted entry; padding entries get zeros.
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
                                                          int F, int cap, int d, int C,
                                                          const float* __restrict__ rowgrad,
                                                          const float* __restrict__ rowgrad1, float* __restrict__ grads,
-                                                         float* __restrict__ grads1) {
+                                                         float* __restrict__ grads1, int ld, int ld1) {
     const int f = blockIdx.y;
     const int grp = threadIdx.x / C, cc = threadIdx.x - grp * C;
     const int gpb = 256 / C;
@@ -182,17 +208,30 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const int* __restrict__
     const long long g = (long long)f * cap + u;
     if (grads) {
         if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(grads + pos * d + cc * 4) = *reinterpret_cast<const float4*>(rowgrad + g * d + cc * 4);
+            *reinterpret_cast<float4*>(grads + pos * ld + cc * 4) = *reinterpret_cast<const float4*>(rowgrad + g * d + cc * 4);
         } else {
-            grads[pos * d + cc] = rowgrad[g * d + cc];
+            grads[pos * ld + cc] = rowgrad[g * d + cc];
         }
     }
-    if (cc == 0 && grads1) grads1[pos] = rowgrad1[g];
+    if (cc == 0 && grads1) grads1[pos * ld1] = rowgrad1[g];
 }
 
-// Owner side: sub-list descriptors for the merge sort from the count slots of the received buckets.
-__global__ void shard_counts_kernel(const long long* __restrict__ recv_idx, int N, int F, const int* __restrict__ capf,
-                                    const int* __restrict__ boff, int S, int* __restrict__ sub_cnt) {
+// Owner side: sub-list descriptors for the merge sort from the count slots of the received buckets -- and, on the
+// workgroups behind those, the requester's slot map (slot_map_entry; grid.x = count blocks + F * ceil(cap / 256)):
+// two small pieces of bookkeeping that both have to be there before rows are served and looked up.
+__global__ __launch_bounds__(256) void shard_counts_kernel(const long long* __restrict__ recv_idx, int N, int F,
+                                                           const int* __restrict__ capf, const int* __restrict__ boff, int S,
+                                                           int* __restrict__ sub_cnt, int count_blocks,
+                                                           const int* __restrict__ sorted_src,
+                                                           const int* __restrict__ entry_seg,
+                                                           const int* __restrict__ counts, const int* __restrict__ route,
+                                                           int cap, int* __restrict__ slot_map, int B, int Fdiv) {
+    if ((int)blockIdx.x >= count_blocks) {
+        const int per = (cap + 255) / 256, b = (int)blockIdx.x - count_blocks;
+        slot_map_entry(sorted_src, entry_seg, counts, route, cap, N * S, slot_map, B, Fdiv, b / per,
+                       (b % per) * 256 + (int)threadIdx.x);
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N * F) {
         const int src = i / F, f = i - src * F;
@@ -236,21 +275,25 @@ int rs_shard_route(const int* plan, int F, int cap, const int64_t* row_offset, i
     return RS_OK;
 }
 
-// Owner: look up the rows named by the received buckets.  rows: [N, S, d]; rows1: [N, S]; cap_max = max capf.
+// Owner: look up the rows named by the received buckets.  rows: [N, S, ld] (ld >= d floats per position); rows1: the
+// 1-dim values, ld1 floats apart (a spare column of the same buffer, or [N, S] with ld1 = 1); cap_max = max capf.
 int rs_shard_gather(const long long* recv_idx, const int64_t* local_row_offset, const int64_t* local_vocab, int N,
                     int F, const int* capf, const int* boff, int S, int cap_max, int d, const float* table,
-                    const float* table1, float* rows, float* rows1, int* err_flag, hipStream_t stream) {
+                    const float* table1, float* rows, float* rows1, int ld, int ld1, int* err_flag, hipStream_t stream) {
     RS_CHECK_ARG(recv_idx && local_row_offset && local_vocab && capf && boff, "rs_shard_gather: null argument");
     RS_CHECK_ARG(N > 0 && F > 0 && S > 0 && cap_max > 0, "rs_shard_gather: bad sizes");
     RS_CHECK_ARG((table == nullptr) == (rows == nullptr) && (table1 == nullptr) == (rows1 == nullptr),
                  "rs_shard_gather: table/rows mismatch");
     int VEC, C;
     RS_CHECK_ARG(lanes(d, &VEC, &C) == 0, "rs_shard_gather: unsupported d=%d", d);
+    RS_CHECK_ARG((!rows || ld >= d) && (!rows1 || ld1 >= 1), "rs_shard_gather: bad row strides");
+    if (VEC == 4 && rows && (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(rows) & 15))) { VEC = 1; C = d; }
+    RS_CHECK_ARG(C <= 256, "rs_shard_gather: rows of %d floats need 16-byte aligned positions", d);
     dim3 grid(rs_cdiv(cap_max, 256 / C), N * F), block(256);
     if (VEC == 4) hipLaunchKernelGGL(shard_gather_kernel<4>, grid, block, 0, stream, recv_idx, local_row_offset, local_vocab,
-                                     F, capf, boff, S, d, C, table, table1, rows, rows1, err_flag);
+                                     F, capf, boff, S, d, C, table, table1, rows, rows1, ld, ld1, err_flag);
     else hipLaunchKernelGGL(shard_gather_kernel<1>, grid, block, 0, stream, recv_idx, local_row_offset, local_vocab, F,
-                            capf, boff, S, d, C, table, table1, rows, rows1, err_flag);
+                            capf, boff, S, d, C, table, table1, rows, rows1, ld, ld1, err_flag);
     RS_CHECK_LAUNCH("rs_shard_gather");
     return RS_OK;
 }
@@ -273,30 +316,77 @@ int rs_shard_expand(const int* plan, const int* route, int F, int cap, int d, co
     return RS_OK;
 }
 
-// Requester: distinct-key gradients (rowgrad [F,cap,d], rowgrad1 [F,cap]) into bucket order.
+// Requester, fused form of the expansion for rows the fused gather takes (d % 4 == 0 and d <= 256, or d <= 64): K1 --
+// rs_gather_lr_fm_fwd, same outputs, same arithmetic -- reading entry (f, b)'s row at position slot_map[f*B + b] of the
+// received row buffer (rows: ld floats per position; rows1: the 1-dim values, ld1 floats apart; either may be null).
+int rs_shard_lookup(const int* slot_map, const float* rows, int ld, const float* rows1, int ld1, const float* bias,
+                    float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out, int B, int F, int d,
+                    hipStream_t stream) {
+    if (B == 0) return RS_OK;
+    RS_CHECK_ARG(slot_map, "rs_shard_lookup: null slot map");
+    RS_CHECK_ARG(B > 0 && F > 0 && d > 0, "rs_shard_lookup: bad sizes B=%d F=%d d=%d", B, F, d);
+    RS_CHECK_ARG(rows || rows1, "rs_shard_lookup: both row buffers are null");
+    RS_CHECK_ARG(rows || !(emb_out || sum_out || bi_out || fm_out), "rs_shard_lookup: embedding outputs requested without rows");
+    RS_CHECK_ARG(rows1 || !lr_out, "rs_shard_lookup: lr_out requested without rows1");
+    RS_CHECK_ARG((!rows || ld >= d) && (!rows1 || ld1 >= 1), "rs_shard_lookup: bad row strides");
+    GatherArgs a{nullptr, nullptr, nullptr, rows, rows1, bias, emb_out, sum_out, bi_out, lr_out, fm_out, nullptr, B, F, d, 1, 1,
+                 slot_map, ld, ld1};
+    int VEC = 1;
+    if (!rows) { VEC = 1; a.C = 1; a.G = 8; a.d = 1; }
+    else {
+        RS_CHECK_ARG(pick_layout(d, &VEC, &a.G, &a.C) == 0, "rs_shard_lookup: unsupported embedding_dim %d", d);
+        if (VEC == 4 && (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(rows) & 15))) {
+            RS_CHECK_ARG(d <= 64, "rs_shard_lookup: rows of %d floats need 16-byte aligned positions", d);
+            VEC = 1; a.C = d; a.G = 8;
+            while (a.G > 1 && a.G * a.C > 32) a.G >>= 1;
+            RS_CHECK_ARG(a.G * a.C <= 64, "rs_shard_lookup: unsupported embedding_dim %d", d);
+        }
+    }
+    const int spw = 64 / (a.G * a.C);
+    const int waves = rs_cdiv(B, spw);
+    dim3 grid(rs_cdiv(waves, 4)), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(shard_lookup_kernel<4>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(shard_lookup_kernel<1>, grid, block, 0, stream, a);
+    RS_CHECK_LAUNCH("rs_shard_lookup");
+    return RS_OK;
+}
+
+// Requester: distinct-key gradients (rowgrad [F,cap,d], rowgrad1 [F,cap]) into bucket order (grads: ld floats per
+// position; grads1: ld1 floats apart).
 int rs_shard_pack(const int* plan, const int* route, int F, int cap, int d, const float* rowgrad,
-                  const float* rowgrad1, float* grads, float* grads1, hipStream_t stream) {
+                  const float* rowgrad1, float* grads, float* grads1, int ld, int ld1, hipStream_t stream) {
     RS_CHECK_ARG(plan && route, "rs_shard_pack: null argument");
     RS_CHECK_ARG((rowgrad == nullptr) == (grads == nullptr) && (rowgrad1 == nullptr) == (grads1 == nullptr),
                  "rs_shard_pack: rowgrad/grads mismatch");
     int VEC, C;
     RS_CHECK_ARG(lanes(d, &VEC, &C) == 0, "rs_shard_pack: unsupported d=%d", d);
+    RS_CHECK_ARG((!grads || ld >= d) && (!grads1 || ld1 >= 1), "rs_shard_pack: bad row strides");
+    if (VEC == 4 && grads && (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(grads) & 15))) { VEC = 1; C = d; }
+    RS_CHECK_ARG(C <= 256, "rs_shard_pack: rows of %d floats need 16-byte aligned positions", d);
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     dim3 grid(rs_cdiv(cap, 256 / C), F), block(256);
     if (VEC == 4) hipLaunchKernelGGL(shard_pack_kernel<4>, grid, block, 0, stream, pv.counts, route, F, cap, d, C,
-                                     rowgrad, rowgrad1, grads, grads1);
+                                     rowgrad, rowgrad1, grads, grads1, ld, ld1);
     else hipLaunchKernelGGL(shard_pack_kernel<1>, grid, block, 0, stream, pv.counts, route, F, cap, d, C, rowgrad,
-                            rowgrad1, grads, grads1);
+                            rowgrad1, grads, grads1, ld, ld1);
     RS_CHECK_LAUNCH("rs_shard_pack");
     return RS_OK;
 }
 
-// Owner: sub_cnt[s*F+f] = count slot of received bucket (s, f), clamped to [0, capf[f]].
+// Owner: sub_cnt[s*F+f] = count slot of received bucket (s, f), clamped to [0, capf[f]].  In the same launch, when
+// slot_map (int32 [F, B]) is given: the requester's map from every entry (f, b) of its sorted batch (plan, route of
+// rs_shard_route, capacity cap) to the position of its key's row among the received rows -- N*S, a row of zeros the
+// caller keeps there, for padding entries and keys that did not fit their bucket; Fdiv: sample = gradient row / Fdiv.
 int rs_shard_counts(const long long* recv_idx, int N, int F, const int* capf, const int* boff, int S, int* sub_cnt,
-                    hipStream_t stream) {
+                    const int* plan, const int* route, int cap, int* slot_map, int B, int Fdiv, hipStream_t stream) {
     RS_CHECK_ARG(recv_idx && sub_cnt && capf && boff && N > 0 && F > 0 && S > 0, "rs_shard_counts: bad arguments");
-    hipLaunchKernelGGL(shard_counts_kernel, dim3(rs_cdiv(N * F, 256)), dim3(256), 0, stream, recv_idx, N, F, capf, boff, S,
-                       sub_cnt);
+    RS_CHECK_ARG(!slot_map || (plan && route && cap > 0 && B > 0 && B <= cap && Fdiv > 0), "rs_shard_counts: bad slot map arguments");
+    const int cb = rs_cdiv(N * F, 256);
+    PlanView pv{};
+    if (slot_map) pv = carve_plan(const_cast<int*>(plan), F, cap);
+    const int sb = slot_map ? F * rs_cdiv(cap, 256) : 0;
+    hipLaunchKernelGGL(shard_counts_kernel, dim3(cb + sb), dim3(256), 0, stream, recv_idx, N, F, capf, boff, S, sub_cnt, cb,
+                       pv.sorted_src, pv.entry_seg, pv.counts, route, cap, slot_map, B, Fdiv);
     RS_CHECK_LAUNCH("rs_shard_counts");
     return RS_OK;
 }

@@ -297,6 +297,7 @@ struct ReduceArgs {
     const float* emb;            // [B*F, d]
     const float* dlr;            // [B]    dL/d(lr logit) per sample (or null): 1-dim gradient
     int Fdiv;                    // sample = gradient-row index / Fdiv (columnar batches)
+    int ldg, ld1g;               // floats between consecutive gradient rows of gout / values of g1src (d and 1 when packed)
     float* chunk_sum;            // [F, cap, d]
     float* chunk_sum1;           // [F, cap] (or null)
     float* rowgrad;              // [F, cap, d]
@@ -346,7 +347,7 @@ __device__ __forceinline__ void chunk_reduce_body(const ReduceArgs& a, int f, in
     float g1 = 0.f;
     if (cid >= 0) {
         const int b = src / a.Fdiv;
-        if (a.gout) ldv<VEC>(a.gout + (long long)src * d + co, g);
+        if (a.gout) ldv<VEC>(a.gout + (long long)src * a.ldg + co, g);
         if (a.dfm) {
             const float sdf = a.dfm[b];
             float sv[VEC], ev[VEC];
@@ -355,7 +356,7 @@ __device__ __forceinline__ void chunk_reduce_body(const ReduceArgs& a, int f, in
 #pragma unroll
             for (int k = 0; k < VEC; ++k) g[k] += sdf * (sv[k] - ev[k]);
         }
-        if (a.g1src) g1 += a.g1src[src];
+        if (a.g1src) g1 += a.g1src[(long long)src * a.ld1g];
         if (a.dlr) g1 += a.dlr[b];
     }
     for (int o = 1; o < a.L; o <<= 1) {
@@ -1144,8 +1145,17 @@ static int fill_reduce(ReduceArgs& a, const int* plan, int F, int cap, int d, in
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     a.sorted_src = pv.sorted_src; a.entry_chunk = pv.entry_chunk; a.chunk_start = pv.chunk_start;
     a.seg_row = pv.seg_row; a.seg_first_chunk = pv.seg_first_chunk; a.counts = pv.counts;
-    a.F = F; a.cap = cap; a.d = d;
+    a.F = F; a.cap = cap; a.d = d; a.ldg = d; a.ld1g = 1;
     return lanes_for(d, VEC, &a.C);
+}
+
+// gradient rows that lie ld_gout / ld_g1 floats apart (0: packed); float4 loads need 16-byte aligned rows
+static int set_grad_strides(ReduceArgs& a, int VEC, int ld_gout, int ld_g1, const float* gout) {
+    if (ld_gout) a.ldg = ld_gout;
+    if (ld_g1) a.ld1g = ld_g1;
+    if (a.ldg < a.d || a.ld1g < 1) return -1;
+    if (VEC == 4 && gout && (a.ldg % 4 != 0 || (reinterpret_cast<uintptr_t>(gout) & 15))) return -1;
+    return 0;
 }
 
 // Number of norm partials rs_sparse_bwd_reduce writes.
@@ -1163,7 +1173,7 @@ int rs_sparse_window(int d) { return window_for(d); }
 int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
                          const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
                          float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1,
-                         float* norm_partials, hipStream_t stream) {
+                         float* norm_partials, int ld_gout, int ld_g1, hipStream_t stream) {
     RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce: null argument");
     RS_CHECK_ARG(!dfm || (S && emb), "rs_sparse_bwd_reduce: dfm needs S and emb");
     RS_CHECK_ARG((chunk_sum1 != nullptr) == (rowgrad1 != nullptr), "rs_sparse_bwd_reduce: chunk_sum1/rowgrad1 mismatch");
@@ -1174,6 +1184,7 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
     a.gout = gout; a.g1src = g1src; a.dfm = dfm; a.S = S; a.emb = emb; a.dlr = dlr; a.Fdiv = Fdiv;
     a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
     a.norm_partials = norm_partials;
+    RS_CHECK_ARG(set_grad_strides(a, VEC, ld_gout, ld_g1, gout) == 0, "rs_sparse_bwd_reduce: bad gradient row strides %d / %d", ld_gout, ld_g1);
     a.L = window_for(d);       // the sort must have been run with the same L (rs_sparse_window(d))
     dim3 grid(rs_cdiv(cap, 256 / a.C), F), block(256);
     dim3 wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F);
@@ -1200,7 +1211,8 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
                                float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
-                               const long long* sk_total, const int* sk_splitk, int sk_count, hipStream_t stream) {
+                               const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                               hipStream_t stream) {
     RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
     RS_CHECK_ARG(cs_count >= 0 && cs_count <= CF_MAX, "rs_sparse_bwd_reduce_sumsq: at most %d column-sum problems", CF_MAX);
     ColsumFinishArgs cf{};
@@ -1229,6 +1241,7 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     a.gout = gout; a.g1src = g1src; a.dfm = dfm; a.S = S; a.emb = emb; a.dlr = dlr; a.Fdiv = Fdiv;
     a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
     a.norm_partials = norm_partials;
+    RS_CHECK_ARG(set_grad_strides(a, VEC, ld_gout, ld_g1, gout) == 0, "rs_sparse_bwd_reduce_sumsq: bad gradient row strides %d / %d", ld_gout, ld_g1);
     a.L = window_for(d);
     const int gx = rs_cdiv(cap, 256 / a.C);
     dim3 block(256), wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F), fgrid(F * gx + n_dense_partials);

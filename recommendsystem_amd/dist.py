@@ -114,27 +114,23 @@ class BucketLayout:
 # -------------------------------------------------------------------------------------------------
 class Comm:
     """torch.distributed wrapper.  stage_cpu=True moves tensors through host memory around each
-    collective (for the gloo backend, which is what the CPU tests and single-GPU rehearsals use)."""
+    collective (for the gloo backend, which is what the CPU tests and single-GPU rehearsals use).
+    Collectives are issued on torch's current stream, like every kernel of the step."""
 
     def __init__(self, group=None, stage_cpu: bool = False):
         self.group = group
         self.stage_cpu = stage_cpu
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.recorder = None         # set while a step is being recorded as HIP-graph segments (see _SegmentRecorder)
+
+    def second(self) -> "Comm":
+        """A communicator of its own over the same ranks: collectives issued through it on another stream run beside
+        those of this one (the dense all-reduce beside the gradient all-to-all).  Collective call: every rank."""
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+        return Comm(dist.new_group(ranks=ranks), stage_cpu=self.stage_cpu)
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
         """Equal split: chunk s of `inp` goes to rank s; chunk s of `out` comes from rank s."""
-        if self.recorder is not None:
-            return self.recorder.collective(lambda: self._all_to_all(out, inp))
-        self._all_to_all(out, inp)
-
-    def all_reduce(self, t: torch.Tensor):
-        if self.recorder is not None:
-            return self.recorder.collective(lambda: self._all_reduce(t))
-        self._all_reduce(t)
-
-    def _all_to_all(self, out, inp):
         if self.stage_cpu and inp.is_cuda:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o.view(-1), inp.cpu().view(-1), group=self.group)
@@ -142,7 +138,7 @@ class Comm:
         else:
             dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
 
-    def _all_reduce(self, t):
+    def all_reduce(self, t: torch.Tensor):
         if self.stage_cpu and t.is_cuda:
             c = t.cpu()
             dist.all_reduce(c, group=self.group)
@@ -160,11 +156,6 @@ class Comm:
 
     def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor):
         """out [world, *inp.shape] (persistent) <- every rank's `inp`, in rank order."""
-        if self.recorder is not None:
-            return self.recorder.collective(lambda: self._all_gather_into(out, inp))
-        self._all_gather_into(out, inp)
-
-    def _all_gather_into(self, out, inp):
         if self.stage_cpu and inp.is_cuda:
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather(list(o.unbind(0)), inp.cpu().contiguous(), group=self.group)
@@ -179,52 +170,18 @@ class Comm:
         return [o.to(t.device) for o in outs]
 
 
-class _SegmentRecorder:
-    """Records one training step as alternating HIP-graph segments and collectives.
-
-    The kernels between two collectives are captured into a HIP graph; the collectives themselves stay ordinary
-    torch.distributed calls issued between the graph replays (nothing of RCCL is captured).  All segments share
-    one memory pool, and every buffer a collective touches is a persistent tensor, so a replay is
-    graph, collective, graph, ... in the recorded order."""
-
-    def __init__(self, pool):
-        self.pool = pool
-        self.plan = []           # ("graph", CUDAGraph) | ("call", closure)
-        self._g = None
-
-    def begin(self):
-        from . import _lib
-        self._calls_at_begin = _lib.n_calls
-        self._g = torch.cuda.CUDAGraph()
-        # thread-local capture mode: the process group's watchdog thread polls its events from another thread, which
-        # must not invalidate this capture
-        self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
-
-    def end(self):
-        self._g.capture_end()
-        self.plan.append(("graph", self._g))
-        self._g = None
-
-    def collective(self, fn):
-        from . import _lib
-        if self.plan and self.plan[-1][0] == "call" and _lib.n_calls == self._calls_at_begin:
-            self.plan.append(("call", fn))  # two collectives back to back: nothing to capture between them
-            return
-        self.end()
-        self.plan.append(("call", fn))      # not executed while recording: no rank runs it, so the ranks stay in step
-        self.begin()
-
-    def replay(self):
-        for kind, obj in self.plan:
-            if kind == "graph":
-                obj.replay()
-            else:
-                obj()
-
-
 # -------------------------------------------------------------------------------------------------
 # device kernels of the exchange (HIP)
 # -------------------------------------------------------------------------------------------------
+def payload_width(d: int, with_emb: bool, with_lr: bool):
+    """(floats per position of the row / gradient buffers, column of the 1-dim value): the d-wide row first; the value
+    of the 1-dim (LR) table travels in a spare column behind it -- four floats wide, so that positions stay 16-byte
+    aligned -- instead of in a buffer and an all-to-all of its own."""
+    if with_emb:
+        return (d + 4, d) if with_lr else (d, 0)
+    return 1, 0
+
+
 class HipShardKernels:
     """The device side of the exchange on librs_hip.so.  tests/test_dist_cpu.py substitutes a torch-CPU
     stand-in with the same methods to rehearse the protocol under gloo."""
@@ -232,6 +189,7 @@ class HipShardKernels:
     def __init__(self, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool, buckets: BucketLayout, device):
         self.spec, self.B, self.d, self.bk = spec, B, d, buckets
         self.with_emb, self.with_lr = with_emb, with_lr
+        self.W, self.lr_col = payload_width(d, with_emb, with_lr)
         self.F = len(spec.vocab)
         self.layout_req = FieldLayout(spec.vocab, device)            # requester: global indices
         self.layout_own = FieldLayout(spec.local_vocab, device)      # owner: local indices (+1 shift)
@@ -241,6 +199,13 @@ class HipShardKernels:
         self.sub_off, self.pay_base = buckets.list_tables(N, device)
         self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
         self.scratch_partials = torch.zeros(self.plan_req.n_partials, dtype=torch.float32, device=device)
+        # where the row of entry (f, b) lies among the received rows (position N*S: the row of zeros)
+        self.slot_map = torch.full((F, B), N * buckets.S, dtype=torch.int32, device=device)
+
+    def _cols(self, buf):
+        """(d-wide rows, 1-dim values) of a [*, W] row or gradient buffer, as the pointers the kernels take."""
+        flat = buf.view(-1)
+        return (flat if self.with_emb else None), (flat[self.lr_col:] if self.with_lr else None)
 
     def sort_batch(self, idx):
         self.plan_req.sort_columnar(idx)
@@ -249,27 +214,58 @@ class HipShardKernels:
         bk = self.bk
         call("rs_shard_route", ptr(self.plan_req.plan), self.F, self.B, ptr(self.layout_req.row_offset_t), self.spec.N,
              ptr(bk.capf_t), ptr(bk.boff_t), bk.S, ptr(send_idx), ptr(route), ptr(overflow), stream())
+        self._route = route
 
-    def gather(self, recv_idx, table, table1, rows, rows1):
-        bk = self.bk
-        call("rs_shard_gather", ptr(recv_idx), ptr(self.layout_own.row_offset_t), ptr(self.layout_own.vocab_t),
-             self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S, bk.cap_max, self.d, ptr(table), ptr(table1),
-             ptr(rows), ptr(rows1), ptr(self.layout_own.err_flag), stream())
-
-    def _counts(self, recv_idx):
+    def counts(self, recv_idx):
+        """Sub-list lengths of the received buckets (once per step, for the catch-up and the merge) and, in the same
+        launch, the requester's slot map."""
         bk = self.bk
         call("rs_shard_counts", ptr(recv_idx), self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S,
-             ptr(self.sub_cnt), stream())
+             ptr(self.sub_cnt), ptr(self.plan_req.plan), ptr(self._route), self.B,
+             ptr(self.slot_map) if self.slot_map is not None else None, self.B, self.F, stream())
+
+    def gather(self, recv_idx, table, table1, pay):
+        bk = self.bk
+        rows, rows1 = self._cols(pay)
+        call("rs_shard_gather", ptr(recv_idx), ptr(self.layout_own.row_offset_t), ptr(self.layout_own.vocab_t),
+             self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S, bk.cap_max, self.d, ptr(table), ptr(table1),
+             ptr(rows), ptr(rows1), self.W, self.W, ptr(self.layout_own.err_flag), stream())
 
     def catch_up(self, recv_idx, rs, rs1):
         """Owner, exact Adam on touched rows: the rows the received buckets name are brought up to the current step
         before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard)."""
-        self._counts(recv_idx)
         ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.bk.cap_max, self.layout_own, rs, rs1)
 
-    def expand(self, route, rows, rows1, emb, lr1):
-        call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(rows),
-             ptr(rows1), ptr(emb), ptr(lr1), stream())
+    def lookup(self, pay, bias, want_emb=True, want_sum=False, want_lr=False, want_fm=False):
+        """The requester's fused lookup in the received rows: dict(emb [B,F,d], sum [B,d], lr [B], fm [B]) as K1 leaves
+        them on one GPU (ops.gather_lr_fm_fwd), entry (f, b) reading the row of its distinct key."""
+        B, F, d = self.B, self.F, self.d
+        rows, rows1 = self._cols(pay)
+        dev = pay.device
+        out = {}
+        if want_emb:
+            out["emb"] = torch.empty((B, F, d), dtype=torch.float32, device=dev)
+        if want_sum:
+            out["sum"] = torch.empty((B, d), dtype=torch.float32, device=dev)
+        if want_lr:
+            out["lr"] = torch.empty((B,), dtype=torch.float32, device=dev)
+        if want_fm:
+            out["fm"] = torch.empty((B,), dtype=torch.float32, device=dev)
+        call("rs_shard_lookup", ptr(self.slot_map), ptr(rows), self.W, ptr(rows1), self.W, ptr(bias), ptr(out.get("emb")),
+             ptr(out.get("sum")), None, ptr(out.get("lr")), ptr(out.get("fm")), B, F, d, stream())
+        return out
+
+    def expand(self, route, pay, emb, lr1):
+        """Per-entry copies of the received rows (emb [B*F, d]) / 1-dim values (lr1 [B*F])."""
+        if emb is not None and lr1 is not None:
+            raise RSError("shard exchange: rows and 1-dim values in one buffer are read through lookup()")
+        if emb is not None:
+            rows, _ = self._cols(pay)
+            call("rs_shard_lookup", ptr(self.slot_map), ptr(rows), self.W, None, 1, None, ptr(emb), None, None, None, None,
+                 self.B, self.F, self.d, stream())
+        else:
+            call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, None, ptr(pay), None,
+                 ptr(lr1), stream())
 
     def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
         """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1).  colsum / splitk: pending
@@ -277,20 +273,22 @@ class HipShardKernels:
         self.plan_req.reduce(self.scratch_partials, gout=gout, dfm=dfm, S=S, emb=emb, dlr=dlr, Fdiv=self.F,
                              colsum=colsum, splitk=splitk)
 
-    def pack(self, route, grads, grads1):
+    def pack(self, route, gbuf):
+        grads, grads1 = self._cols(gbuf)
         call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d,
              ptr(self.plan_req.rowgrad) if grads is not None else None,
-             ptr(self.plan_req.rowgrad1) if grads1 is not None else None, ptr(grads), ptr(grads1), stream())
+             ptr(self.plan_req.rowgrad1) if grads1 is not None else None, ptr(grads), ptr(grads1), self.W, self.W, stream())
 
-    def merge(self, recv_idx, grads, grads1, partials):
-        """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows."""
+    def merge(self, recv_idx, gbuf, partials, dense=None, dense_partials=None):
+        """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows.  dense / dense_partials:
+        the sum-of-squares partials of that flat buffer come out of the reduction's second launch as well."""
         N = self.spec.N
-        self._counts(recv_idx)
+        grads, grads1 = self._cols(gbuf)
         # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
         self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
                                   max_entries=N * self.bk.cap_max)
-        self.plan_own.reduce(partials, gout=grads.view(-1, self.d) if grads is not None else None,
-                             g1src=grads1.view(-1) if grads1 is not None else None, Fdiv=1)
+        self.plan_own.reduce(partials, gout=grads, g1src=grads1, Fdiv=1, ld_gout=self.W if grads is not None else 0,
+                             ld_g1=self.W if grads1 is not None else 0, dense=dense, dense_partials=dense_partials)
 
     def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, dense=None, rs=None, rs1=None):
         """Touched-rows step on the shard; dense = (w, g, m, v): the flat dense step in the same launch."""
@@ -312,6 +310,7 @@ class HipShardKernelsWide(HipShardKernels):
     def __init__(self, spec: ShardSpec, B: int, W: int, buckets: BucketLayout, device):
         self.spec, self.B, self.d, self.bk = spec, B, W, buckets
         self.with_emb, self.with_lr = True, False
+        self.W, self.lr_col = W, 0
         self.F = len(spec.vocab)
         self.layout_req = FieldLayout(spec.vocab, device)
         self.layout_own = FieldLayout(spec.local_vocab, device)
@@ -321,21 +320,34 @@ class HipShardKernelsWide(HipShardKernels):
         self.sub_off, self.pay_base = buckets.list_tables(N, device)
         self.sub_cnt = torch.zeros(N * F, dtype=torch.int32, device=device)
         self.scratch_partials = torch.zeros(self.plan_req.n_partials_wide, dtype=torch.float32, device=device)
+        self.slot_map = None
+
+    def route(self, send_idx, route, overflow):
+        bk = self.bk
+        call("rs_shard_route", ptr(self.plan_req.plan), self.F, self.B, ptr(self.layout_req.row_offset_t), self.spec.N,
+             ptr(bk.capf_t), ptr(bk.boff_t), bk.S, ptr(send_idx), ptr(route), ptr(overflow), stream())
+        self._route = route
+
+    def lookup(self, *a, **k):
+        raise RSError("wide rows are expanded, not looked up")
+
+    def expand(self, route, pay, emb, lr1):
+        call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(pay), None, ptr(emb), None,
+             stream())
 
     def reduce_local(self, gout, dfm, S, emb, dlr):
         self.plan_req.reduce_wide(self.scratch_partials, gout)
 
-    def pack(self, route, grads, grads1):
+    def pack(self, route, gbuf):
         call("rs_shard_pack", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d,
-             ptr(self.plan_req.rowgrad_wide), None, ptr(grads), None, stream())
+             ptr(self.plan_req.rowgrad_wide), None, ptr(gbuf), None, self.W, 1, stream())
 
-    def merge(self, recv_idx, grads, grads1, partials):
+    def merge(self, recv_idx, gbuf, partials):
         N = self.spec.N
-        self._counts(recv_idx)
         # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
         self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
                                   max_entries=N * self.bk.cap_max)
-        self.plan_own.reduce_wide(partials, grads.view(-1, self.d))
+        self.plan_own.reduce_wide(partials, gbuf.view(-1, self.d))
 
     def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, rs=None, rs1=None):
         self.plan_own.update_wide(opt, hyper, scal, table, m, v, rs=rs)
@@ -349,6 +361,9 @@ class HipShardKernelsWide(HipShardKernels):
 # the exchange protocol
 # -------------------------------------------------------------------------------------------------
 class ShardedExchange:
+    """Three all-to-alls per step and table set: distinct keys out, rows back, one gradient per distinct key out.
+    Rows and gradients of the d-wide table and of the 1-dim (LR) table share one buffer (payload_width)."""
+
     def __init__(self, kernels, comm: Comm, spec: ShardSpec, B: int, d: int, with_emb: bool, with_lr: bool,
                  buckets: BucketLayout, device):
         self.k, self.comm, self.spec = kernels, comm, spec
@@ -357,50 +372,63 @@ class ShardedExchange:
         self.with_emb, self.with_lr = with_emb, with_lr
         dev = device
         S = buckets.S
+        W = kernels.W
+        self.W = W
         z = lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
         self.send_idx = z((N, S + F), torch.int64)
         self.recv_idx = z((N, S + F), torch.int64)
         self.route = torch.full((F, B), -1, dtype=torch.int32, device=dev)
         self.overflow = z((1,), torch.int32)
-        self.rows_s = z((N, S, d)) if with_emb else None
-        self.rows_r = z((N, S, d)) if with_emb else None
-        self.rows1_s = z((N, S)) if with_lr else None
-        self.rows1_r = z((N, S)) if with_lr else None
-        # gradient buffers reuse the row buffers' shapes
-        self.g_s = z((N, S, d)) if with_emb else None
-        self.g_r = z((N, S, d)) if with_emb else None
-        self.g1_s = z((N, S)) if with_lr else None
-        self.g1_r = z((N, S)) if with_lr else None
+        self.pay_s = z((N * S, W))
+        self.pay_r = z((N * S + 1, W))          # position N*S stays zero: what padding entries and lost keys read
+        self.g_s = z((N * S, W))
+        self.g_r = z((N * S, W))
 
-    def forward(self, idx, table, table1, emb_out, lr1_out, rs=None, rs1=None):
-        """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values.  rs / rs1: ops.RowAdam of
-        table / table1 when the owner replays skipped Adam steps of the requested rows before serving them."""
+    # ---- forward, in the three pieces a trainer may interleave with other work -----------------------------
+    def send_keys(self, idx):
+        """Requester: sort + de-duplicate the batch, bucket its distinct keys by owner, exchange them."""
         k, c = self.k, self.comm
         k.sort_batch(idx)
         k.route(self.send_idx, self.route, self.overflow)
         c.all_to_all(self.recv_idx, self.send_idx)
+        if hasattr(k, "counts"):
+            k.counts(self.recv_idx)
+
+    def serve_rows(self, table, table1, rs=None, rs1=None):
+        """Owner: bring the requested rows up to date (exact Adam), look them up, send them back."""
+        k, c = self.k, self.comm
         if rs is not None or rs1 is not None:
             k.catch_up(self.recv_idx, rs, rs1)
-        k.gather(self.recv_idx, table, table1, self.rows_s, self.rows1_s)
-        if self.with_emb:
-            c.all_to_all(self.rows_r, self.rows_s)
-        if self.with_lr:
-            c.all_to_all(self.rows1_r, self.rows1_s)
-        k.expand(self.route, self.rows_r, self.rows1_r, emb_out, lr1_out)
+        k.gather(self.recv_idx, table, table1, self.pay_s)
+        c.all_to_all(self.pay_r[:self.N * self.bk.S], self.pay_s)
+
+    def forward(self, idx, table, table1, emb_out, lr1_out, rs=None, rs1=None):
+        """idx [F,B] global indices -> emb_out [B*F, d] rows, lr1_out [B*F] 1-dim values.  rs / rs1: ops.RowAdam of
+        table / table1 when the owner replays skipped Adam steps of the requested rows before serving them."""
+        self.send_keys(idx)
+        self.serve_rows(table, table1, rs, rs1)
+        self.k.expand(self.route, self.pay_r, emb_out, lr1_out)
 
     def backward(self, gout, dfm, S, emb, dlr, own_partials, colsum=None, splitk=None):
         """Per-entry gradient terms of the local batch -> summed row gradients on the owners."""
-        k, c = self.k, self.comm
+        self.reduce_local(gout, dfm, S, emb, dlr, colsum=colsum, splitk=splitk)
+        self.send_grads(own_partials)
+
+    def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
         if colsum is not None or splitk is not None:
-            k.reduce_local(gout, dfm, S, emb, dlr, colsum=colsum, splitk=splitk)
+            self.k.reduce_local(gout, dfm, S, emb, dlr, colsum=colsum, splitk=splitk)
         else:
-            k.reduce_local(gout, dfm, S, emb, dlr)
-        k.pack(self.route, self.g_s, self.g1_s)
-        if self.with_emb:
-            c.all_to_all(self.g_r, self.g_s)
-        if self.with_lr:
-            c.all_to_all(self.g1_r, self.g1_s)
-        k.merge(self.recv_idx, self.g_r, self.g1_r, own_partials)
+            self.k.reduce_local(gout, dfm, S, emb, dlr)
+
+    def send_grads(self, own_partials, before_merge=None, **merge_kw):
+        """before_merge: called between the all-to-all and the owner's reduction (a collective of the caller's that
+        the reduction's launches then build on)."""
+        k, c = self.k, self.comm
+        k.pack(self.route, self.g_s)
+        c.all_to_all(self.g_r, self.g_s)
+        if before_merge is not None:
+            before_merge()
+        k.merge(self.recv_idx, self.g_r, own_partials, **merge_kw)
 
     def check_overflow(self):
         """Host check (device sync): a bucket overflow drops rows; raise so the caller can re-plan."""
@@ -408,6 +436,19 @@ class ShardedExchange:
             self.overflow.zero_()
             raise RSError("row-shard exchange: a (rank, field) bucket overflowed its capacity; "
                           "raise bucket_slack")
+
+
+def _capture_with_collectives(trainer, idx, labels):
+    """FusedTrainer._capture for a step with RCCL collectives inside.  The warm-up steps (and the first replay) run for
+    real -- collectives included, on every rank -- and are undone.  Other threads of the process group (its watchdog)
+    keep working during capture, hence the thread-local capture mode; the watchdog is given time to retire the
+    collectives issued so far before the capture begins (it polls their events, and must not find one that the capture
+    has taken over)."""
+    import time
+    trainer._capture_error_mode = "thread_local"
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    return FusedTrainer._capture(trainer, idx, labels)
 
 
 def _reject_batchnorm(model, who: str):
@@ -428,20 +469,38 @@ class DistributedTrainer(FusedTrainer):
     Every rank must build the same model from the same seed before constructing the trainer; the
     trainer keeps only this rank's shard of each table as training state.  ``sync_to_model()``
     all-gathers the shards back into the model's parameters (for evaluation / checkpoints).
+
+    One step, after the dense backward:  the requester's reduction (one gradient per distinct key; the finishing sums
+    of the dense gradients ride in its launch) -> on a second stream and a second communicator the all-reduce of the flat
+    dense gradient and its norm partials, beside, on the main stream, pack -> all-to-all of the gradients -> owner-side
+    merge + reduction -> all-reduce of the owners' ||g||^2 partials -> join -> clip coefficient -> ONE launch for the
+    shard update and the dense update.  use_graph: the whole step, collectives included, is one HIP graph.
     """
 
     def __init__(self, model, mode: str = "sparse", use_graph: bool = False, group=None, stage_cpu: bool = False,
-                 bucket_slack: float = 1.5, **kw):
+                 bucket_slack: float = 1.5, overlap_comm: Optional[bool] = None, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
         _reject_batchnorm(model, "DistributedTrainer")
+        if use_graph and stage_cpu:
+            raise RSError("DistributedTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
         super().__init__(model, mode="sparse", use_graph=use_graph, **kw)
+        if self.overlap:
+            raise RSError("DistributedTrainer: side streams for the weight gradients (overlap) do not go with the exchange")
         self._sort_can_fork = False
         self._update_shares_launch = True
         self._reduce_carries_finishes = True
+        # the all-reduce of the dense gradient on a stream and a communicator of its own, beside the gradient exchange
+        # (default: with more than one rank -- alone, a rank's all-reduce is a copy and there is nothing to hide)
+        self.overlap_comm = self.world > 1 if overlap_comm is None else bool(overlap_comm)
+        self.comm_dense = self.comm.second() if self.overlap_comm else self.comm
+        self.side_comm = torch.cuda.Stream(device=self.device) if self.overlap_comm else None
+        self.ws_comm = ops.Workspace(self.device)
+        # a bucket that overflows serves zeros for the keys it lost: look at the flag often
+        self.check_every = 16
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments
@@ -465,7 +524,6 @@ class DistributedTrainer(FusedTrainer):
                 self.rs_shard1 = ops.RowAdam(self.shard1, self.shard1_m, self.shard1_v, self.opt, self.hyper, self.step_count,
                                              bctab=self.rs_shard.bctab if self.rs_shard is not None else None)
         self._ex = {}
-        self.ones_F = torch.ones(self.F, dtype=torch.float32, device=self.device)
         # the dense tower must start identical on every rank
         self.comm.broadcast(self.flat_w, 0)
 
@@ -474,8 +532,11 @@ class DistributedTrainer(FusedTrainer):
             bk = self.spec.buckets(B, slack=self.bucket_slack, device=self.device)
             k = HipShardKernels(self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
             ex = ShardedExchange(k, self.comm, self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
-            ex.own_partials = torch.zeros(k.n_own_partials, dtype=torch.float32, device=self.device)
-            ex.sq = torch.zeros(1, dtype=torch.float32, device=self.device)
+            # the partial sums of the global gradient norm, in one buffer: ||g||^2 of the rows this rank owns (summed
+            # over ranks by an all-reduce of its own: ranks own disjoint rows), then those of the flat dense gradient
+            ex.norm_buf = torch.zeros(k.n_own_partials + N_DENSE_PARTIALS, dtype=torch.float32, device=self.device)
+            ex.own_partials = ex.norm_buf[:k.n_own_partials]
+            ex.dense_partials = ex.norm_buf[k.n_own_partials:]
             self._ex[B] = ex
         return self._ex[B]
 
@@ -495,90 +556,58 @@ class DistributedTrainer(FusedTrainer):
                 rs.flush()
 
     def _embed_forward(self, idx):
-        B = idx.shape[1]
-        ex = self.exchange(B)
-        dev = self.device
-        emb = torch.empty((B, self.F, self.d), dtype=torch.float32, device=dev) if self.has_emb else None
-        lr1 = torch.empty((B, self.F), dtype=torch.float32, device=dev) if self.has_lr else None
-        ex.forward(idx, self.shard, self.shard1, emb.view(B * self.F, self.d) if emb is not None else None,
-                   lr1.view(-1) if lr1 is not None else None, rs=self.rs_shard, rs1=self.rs_shard1)
-        r = {"emb": emb}
-        if self.has_fm:
-            r.update(ops.fm_fwd(emb, want_sum=True, want_fm=True))
-        if self.has_lr:
-            r["lr"] = ops.rowdot_fwd(lr1, self.ones_F, self.lrm.bias.data, 0)     # sum_f w_f[idx] + bias
-        return r
+        """K1 through the exchange: distinct keys out, rows back, then the fused lookup in the received rows."""
+        ex = self.exchange(idx.shape[1])
+        ex.send_keys(idx)
+        ex.serve_rows(self.shard, self.shard1, rs=self.rs_shard, rs1=self.rs_shard1)
+        return ex.k.lookup(ex.pay_r, self.lrm.bias.data if self.has_lr else None, want_emb=self.has_emb,
+                           want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
 
     def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None, splitk=None):
         B = idx.shape[1]
         ex = self.exchange(B)
-        ex.backward(gout, dz if self.has_fm else None, ctx["S"],
-                    ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
-                    ex.own_partials, colsum=colsum, splitk=splitk)
-        # ||g||^2 of the owned rows (every rank owns disjoint rows) rides behind the dense gradients in the
-        # one all-reduce of the step
-        ops.colsum(ex.own_partials.view(-1, 1), out=self.flat_g_ext[-4:-3])
-        self._cur_plan = plan
+        ex.reduce_local(gout, dz if self.has_fm else None, ctx["S"],
+                        ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
+                        colsum=colsum, splitk=splitk)
+        # the flat dense gradient is final from here on (its finishing sums rode in the launch above)
+        if self.overlap_comm:
+            main = torch.cuda.current_stream()
+            self.side_comm.wait_stream(main)
+            with torch.cuda.stream(self.side_comm), ops.use_workspace(self.ws_comm):
+                self._dense_grad_norm(ex)
+            ex.send_grads(ex.own_partials)
+            self.comm.all_reduce(ex.own_partials)
+            main.wait_stream(self.side_comm)
+        else:
+            # one stream: the dense gradient is summed over ranks in front of the owner's reduction, whose second
+            # launch then also leaves its norm partials
+            ex.send_grads(ex.own_partials, before_merge=lambda: self._dense_grad_norm(ex, sumsq=False),
+                          dense=self.flat_g, dense_partials=ex.dense_partials)
+            self.comm.all_reduce(ex.own_partials)
+        self._cur_ex = ex
 
-    def _reduce_dense_grads(self):
-        self.comm.all_reduce(self.flat_g_ext)
-        # the base plan's table partials are written by nobody on this path (the exchange reduces on its own plans), so
-        # they stay zero from allocation on; slot 0 carries the all-reduced ||g||^2 of the sharded tables
-        self._cur_plan.partials[0:1].copy_(self.flat_g_ext[-4:-3])
+    def _dense_grad_norm(self, ex, sumsq=True):
+        """Sum the flat dense gradient over ranks; its L2 term; its sum-of-squares partials."""
+        self.comm_dense.all_reduce(self.flat_g)
+        if self.net_reg:
+            ops.axpy(self.net_reg, self.flat_w, self.flat_g)
+        if sumsq:
+            ops.sumsq_partials(self.flat_g, ex.dense_partials)
 
-    def _embed_update(self, plan, with_dense=False):
-        # `plan` is the base class's per-batch-size plan (its partial buffer carries the norm); the update
-        # runs on the owner-side plan of the exchange
+    def _grad_norm_partials(self, plan, fuse, dense_p):
+        return self._cur_ex.norm_buf
+
+    def _embed_update(self, plan, with_dense=False, stamps=True, next_plan=None):
+        # `plan` is the base class's per-batch-size plan; the update runs on the owner-side plan of the exchange
         ex = self._ex[plan.cap]
         ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
                     self.shard1_m, self.shard1_v,
                     dense=(self.flat_w, self.flat_g, self.flat_m, self.flat_v) if with_dense else None,
                     rs=self.rs_shard, rs1=self.rs_shard1)
 
-    # ---- HIP-graph segments between the collectives --------------------------------------------------
+    # ---- the whole step as one HIP graph, collectives inside --------------------------------------------
     def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
-        """Record one step reading `idx`/`labels` in place as graph segments + collectives; the training state is
-        left as it was (the warm-up steps run for real -- collectives included, on every rank -- and are undone).
-        use_graph="full": one HIP graph for the whole step with the RCCL collectives captured inside it (other
-        threads of the process group, such as its watchdog, keep working during capture)."""
-        if self.use_graph == "full":
-            self._capture_error_mode = "thread_local"
-            return FusedTrainer._capture(self, idx, labels)
-        ent = {"idx": idx, "labels": labels, "ahead_after": None}
-        snap = [(t, t.clone()) for t in self._mutable_state()]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s), ops.use_workspace(self.ws):
-            for _ in range(2):
-                self._step_impl(idx, labels)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        for t, c in snap:
-            t.copy_(c)
-        if self._graph_pool is None:
-            self._graph_pool = torch.cuda.graph_pool_handle()
-        rec = _SegmentRecorder(self._graph_pool)
-        with torch.cuda.stream(s), ops.use_workspace(self.ws):
-            self.comm.recorder = rec
-            try:
-                rec.begin()
-                ent["loss"] = self._step_impl(idx, labels)
-                rec.end()
-            finally:
-                self.comm.recorder = None
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        for t, c in snap:
-            t.copy_(c)
-
-        class _Replay:
-            def __init__(self, r):
-                self.r = r
-
-            def replay(self):
-                self.r.replay()
-        ent["graph"] = _Replay(rec)
-        return ent
+        return _capture_with_collectives(self, idx, labels)
 
     def _mutable_state(self):
         ts = super()._mutable_state()
@@ -699,6 +728,8 @@ class ReplicatedTablesTrainer(FusedTrainer):
 
     def __init__(self, model, use_graph: bool = False, group=None, stage_cpu: bool = False, **kw):
         _reject_batchnorm(model, "ReplicatedTablesTrainer")
+        if use_graph and stage_cpu:
+            raise RSError("ReplicatedTablesTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         kw.pop("mode", None)
@@ -742,7 +773,8 @@ class ReplicatedTablesTrainer(FusedTrainer):
     def _embed_update(self, plan, with_dense=False):
         FusedTrainer._embed_update(self, self._rp[plan.cap].k.gplan, with_dense=with_dense)
 
-    _capture = DistributedTrainer._capture
+    def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
+        return _capture_with_collectives(self, idx, labels)
 
     def sync_to_model(self):
         """Nothing to gather: the model's tables are this rank's replica (rows left behind are brought up to date)."""

@@ -399,6 +399,17 @@ class FusedTrainer:
     def _reduce_dense_grads(self):
         """Multi-GPU: sum the flat dense gradient over ranks.  Single GPU: nothing."""
 
+    def _grad_norm_partials(self, plan, fuse, dense_p):
+        """Touched-rows mode, between the embedding backward and the clip coefficient: whatever the dense gradient still
+        needs (its sum over ranks, its L2 term, its sum-of-squares partials unless they came out of the embedding
+        reduction's launch); returns the buffer of partial sums whose total is the squared global gradient norm."""
+        self._reduce_dense_grads()
+        if self.net_reg:
+            ops.axpy(self.net_reg, self.flat_w, self.flat_g)
+        if not fuse:
+            ops.sumsq_partials(self.flat_g, dense_p)
+        return plan.partials[:plan.n_partials + N_DENSE_PARTIALS]
+
     def _embed_update(self, plan, with_dense=False, stamps=True, next_plan=None):
         te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
         kw = dict(table=te["w"] if te else None, m=te["m"] if te else None, v=te["v"] if te else None,
@@ -662,14 +673,13 @@ class FusedTrainer:
         if overlap:
             main.wait_stream(self.side_w)       # every dense gradient is in flat_g from here on
         # ---- L2 terms, global norm, clip coefficient ------------------------------------------
-        self._reduce_dense_grads()
-        if self.net_reg:
-            ops.axpy(self.net_reg, self.flat_w, self.flat_g)
-        if not fuse:
-            ops.sumsq_partials(self.flat_g, dense_p)
         if self.mode == "sparse":
-            norm_in = P[:n_sp + N_DENSE_PARTIALS]
+            norm_in = self._grad_norm_partials(plan, fuse, dense_p)
         else:
+            self._reduce_dense_grads()
+            if self.net_reg:
+                ops.axpy(self.net_reg, self.flat_w, self.flat_g)
+            ops.sumsq_partials(self.flat_g, dense_p)
             off = n_sp + N_DENSE_PARTIALS
             for t in self.tables:
                 t["g"].zero_()
@@ -831,8 +841,10 @@ class FusedTrainer:
         ent["ahead_after"] = self._ahead
         if self._graph_pool is None:
             self._graph_pool = g.pool()
+        # the first launch of a graph pays for its instantiation on the device (some 0.1 ms): pay it here
+        g.replay()
         torch.cuda.synchronize()
-        for t, c in snap:       # capture does not execute, but keep the state exactly as before
+        for t, c in snap:       # keep the state exactly as before
             t.copy_(c)
         self._ahead = dict(entry) if entry else None
         ent["graph"] = g

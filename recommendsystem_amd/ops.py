@@ -888,14 +888,20 @@ class SparsePlan:
              ptr(self.plan), stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
-               Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None):
+               Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None, ld_gout: int = 0, ld_g1: int = 0):
         """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats).  dense / dense_partials: also
         write the sum-of-squares partials of the flat buffer `dense` (one per element of dense_partials) from the
         same launch.  colsum / splitk: ColsumParts.hand_over() / SplitKParts.hand_over() -- those run beside the first launch."""
         if norm_partials.numel() < self.n_partials:
             raise RSError("sparse backward: norm_partials too small")
+        # ld_gout / ld_g1: gout / g1src are columns of a wider buffer (floats between consecutive rows / values)
         for t, n in ((gout, "gout"), (g1src, "g1src"), (dfm, "dfm"), (S, "S"), (emb, "emb"), (dlr, "dlr")):
-            _chk(t, torch.float32, n)
+            if t is not None and ((t is gout and ld_gout) or (t is g1src and ld_g1)):
+                if t.dtype != torch.float32:
+                    raise RSError(f"{n}: expected dtype torch.float32, got {t.dtype}")
+                require_cuda(t)
+            else:
+                _chk(t, torch.float32, n)
         if dense is not None or colsum is not None or splitk is not None:
             if dense is not None:
                 _chk(dense, torch.float32, "dense")
@@ -905,11 +911,11 @@ class SparsePlan:
                  ptr(self.rowgrad), ptr(self.rowgrad1), ptr(norm_partials), ptr(dense),
                  dense.numel() if dense is not None else 0, ptr(dense_partials if dense is not None else None),
                  dense_partials.numel() if dense is not None else 0, *(colsum or (None, None, None, None, None, 0)),
-                 *(splitk or (None, None, None, None, 0)), stream())
+                 *(splitk or (None, None, None, None, 0)), int(ld_gout), int(ld_g1), stream())
             return
         call("rs_sparse_bwd_reduce", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm), ptr(S),
              ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1), ptr(self.rowgrad),
-             ptr(self.rowgrad1), ptr(norm_partials), stream())
+             ptr(self.rowgrad1), ptr(norm_partials), int(ld_gout), int(ld_g1), stream())
 
     @staticmethod
     def _stamps(rs, rs1):

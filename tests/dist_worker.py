@@ -1,10 +1,13 @@
 """One rank of the multi-process tests (started by test_dist_cpu.py / test_dist_gpu.py).
 
     python dist_worker.py cpu <outdir>     host-side exchange protocol under gloo with torch-CPU stand-in kernels
-    python dist_worker.py gpu <outdir> <kind> <optimizer> [graph|generic]
-                                           DistributedTrainer (generic: DistributedSparseTrainer) on cuda:0 (all
-                                           ranks share the one GPU of the test box), gloo with host staging in
-                                           place of RCCL
+    python dist_worker.py gpu <outdir> <kind> <optimizer> [onestream|generic|replicated]
+                                           DistributedTrainer (generic: DistributedSparseTrainer; replicated:
+                                           ReplicatedTablesTrainer) on cuda:0 (all ranks share the one GPU of the test
+                                           box), gloo with host staging in place of RCCL
+    python dist_worker.py gpu1 <outdir> <kind> <optimizer>
+                                           one rank with the real RCCL backend: eager, whole-step HIP graph, graph with
+                                           the second stream, replicated tables
 
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment.
 """
@@ -210,7 +213,37 @@ def build_gpu_model(kind, optimizer, batch):
     return m
 
 
-def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False, replicated=False):
+def run_gpu1(outdir, kind, optimizer):
+    """One rank, RCCL: the same three steps eagerly, from one HIP graph, from that graph with the second stream, and
+    with replicated tables from a graph."""
+    from recommendsystem_amd.dist import DistributedTrainer, ReplicatedTablesTrainer
+    torch.cuda.set_device(0)
+    vocab, batch, steps = GPU_VOCAB, GPU_BATCH, GPU_STEPS
+    for name, cls, kw in (("eager", DistributedTrainer, dict(use_graph=False, overlap_comm=False)),
+                          ("graph", DistributedTrainer, dict(use_graph=True, overlap_comm=False)),
+                          ("graph_overlap", DistributedTrainer, dict(use_graph=True, overlap_comm=True)),
+                          ("replicated_graph", ReplicatedTablesTrainer, dict(use_graph=True))):
+        m = build_gpu_model(kind, optimizer, batch)
+        eng = cls(m, max_norm=0.05, optimizer_type=optimizer, **kw)
+        losses = []
+        for s in range(steps):
+            idx, y = rank_batch(10 * s, vocab, batch, zero_every=17)
+            losses.append(float(eng.step_tensors(idx.cuda(), y.cuda()).item()))
+        eng.check()
+        eng.sync_to_model()
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        sd["__losses__"] = np.array(losses)
+        np.savez(os.path.join(outdir, f"state_{name}.npz"), **sd)
+        # graphs that captured collectives go before the communicator does
+        getattr(eng, "_graphs", {}).clear()
+        del eng, m
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+    open(os.path.join(outdir, "ok0"), "w").write("ok")
+
+
+def run_gpu(outdir, kind, optimizer, generic=False, replicated=False, overlap_comm=True):
     from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer, ReplicatedTablesTrainer
     rank, N = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -219,13 +252,13 @@ def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False, replicated=
     if generic:
         eng = DistributedSparseTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
     elif replicated:
-        eng = ReplicatedTablesTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
+        eng = ReplicatedTablesTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer)
     else:
-        eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, use_graph=use_graph)
+        eng = DistributedTrainer(m, max_norm=0.05, stage_cpu=True, optimizer_type=optimizer, overlap_comm=overlap_comm)
     losses = []
     for s in range(steps):
         idx, y = rank_batch(rank + 10 * s, vocab, batch, zero_every=17)
-        loss = eng.step_tensors(idx.cuda(), y.cuda())      # with use_graph: recorded once, then replayed with copies
+        loss = eng.step_tensors(idx.cuda(), y.cuda())
         losses.append(float(loss.item()))
     eng.check()
     eng.sync_to_model()
@@ -238,15 +271,21 @@ def run_gpu(outdir, kind, optimizer, use_graph=False, generic=False, replicated=
 
 if __name__ == "__main__":
     mode, outdir = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    if mode == "gpu1":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     try:
         if mode == "cpu":
             run_cpu(outdir)
         elif mode == "cpu_replica":
             run_cpu_replica(outdir)
+        elif mode == "gpu1":
+            run_gpu1(outdir, sys.argv[3], sys.argv[4])
         else:
             extra = sys.argv[5] if len(sys.argv) > 5 else ""
-            run_gpu(outdir, sys.argv[3], sys.argv[4], use_graph=extra in ("graph", "replicated_graph"),
-                    generic=extra == "generic", replicated=extra.startswith("replicated"))
+            run_gpu(outdir, sys.argv[3], sys.argv[4], generic=extra == "generic", replicated=extra.startswith("replicated"),
+                    overlap_comm=extra != "onestream")
     finally:
         dist.destroy_process_group()

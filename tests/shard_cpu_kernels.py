@@ -1,8 +1,9 @@
 """Torch-CPU stand-in for recommendsystem_amd.dist.HipShardKernels (test infrastructure only).
 
 Same methods and the same buffer layouts (dist.BucketLayout: key buffers [N, S + F] with bucket (o, f) at
-o*(S+F) + boff[f] + f, count slot first; row buffers [N, S, d]; route = position o*S + boff[f] + r), written as plain
-loops, so that the host-side exchange protocol
+o*(S+F) + boff[f] + f, count slot first; row / gradient buffers [N*S (+ a zero row), W] with the d-wide row in the
+first columns and the 1-dim value in column lr_col (dist.payload_width); route = position o*S + boff[f] + r), written
+as plain loops, so that the host-side exchange protocol
 (ShardedExchange + Comm + ShardSpec) can be rehearsed with the gloo backend on a machine without a GPU.
 """
 import torch
@@ -10,9 +11,11 @@ import torch
 
 class TorchShardKernels:
     def __init__(self, spec, B, d, with_emb, with_lr, buckets):
+        from recommendsystem_amd.dist import payload_width
         self.spec, self.B, self.d, self.bk = spec, B, d, buckets
         self.F = len(spec.vocab)
         self.with_emb, self.with_lr = with_emb, with_lr
+        self.W, self.lr_col = payload_width(d, with_emb, with_lr)
         self.local_off = [0]
         for v in spec.local_vocab[:-1]:
             self.local_off.append(self.local_off[-1] + v)
@@ -51,10 +54,10 @@ class TorchShardKernels:
                 send_idx[o, k0 + 1:k0 + 1 + n] = keys[sel[:n]] // N + 1
                 route[f, sel[:n]] = (o * bk.S + bk.boff[f] + torch.arange(n)).to(route.dtype)
 
-    def expand(self, route, rows, rows1, emb, lr1):
+    def expand(self, route, pay, emb, lr1):
         F, B = self.F, self.B
-        rows_f = rows.reshape(-1, rows.shape[-1]) if rows is not None else None
-        rows1_f = rows1.reshape(-1) if rows1 is not None else None
+        rows_f = pay[:, :self.d] if self.with_emb else None
+        rows1_f = pay[:, self.lr_col] if self.with_lr else None
         for f in range(F):
             for b in range(B):
                 u = int(self.entry_seg[f, b])
@@ -91,45 +94,45 @@ class TorchShardKernels:
                 if dlr is not None:
                     self.rowgrad1[f, u] += dlr[b]
 
-    def pack(self, route, grads, grads1):
-        grads_f = grads.view(-1, grads.shape[-1]) if grads is not None else None
-        grads1_f = grads1.view(-1) if grads1 is not None else None
+    def pack(self, route, gbuf):
         for f in range(self.F):
             for u in range(self.seg_keys[f].numel()):
                 code = int(route[f, u])
                 if code < 0:
                     continue
-                if grads is not None:
-                    grads_f[code] = self.rowgrad[f, u]
-                if grads1 is not None:
-                    grads1_f[code] = self.rowgrad1[f, u]
+                if self.with_emb:
+                    gbuf[code, :self.d] = self.rowgrad[f, u]
+                if self.with_lr:
+                    gbuf[code, self.lr_col] = self.rowgrad1[f, u]
 
     # owner -------------------------------------------------------------------------------------
-    def gather(self, recv_idx, table, table1, rows, rows1):
+    def gather(self, recv_idx, table, table1, pay):
+        S = self.bk.S
         for s in range(self.spec.N):
             for f in range(self.F):
-                k0, r0 = self._key_slot(s, f), self.bk.boff[f]
+                k0, r0 = self._key_slot(s, f), s * S + self.bk.boff[f]
                 n = int(recv_idx[s, k0])
                 li = recv_idx[s, k0 + 1:k0 + 1 + n] + self.local_off[f]
-                if rows is not None:
-                    rows[s, r0:r0 + n] = table[li]
-                if rows1 is not None:
-                    rows1[s, r0:r0 + n] = table1[li]
+                if self.with_emb:
+                    pay[r0:r0 + n, :self.d] = table[li]
+                if self.with_lr:
+                    pay[r0:r0 + n, self.lr_col] = table1[li]
 
-    def merge(self, recv_idx, grads, grads1, partials):
+    def merge(self, recv_idx, gbuf, partials):
         """Dense local-table gradients (own_grad, own_grad1) = sum of the N requesters' contributions."""
         R = sum(self.spec.local_vocab)
+        S = self.bk.S
         self.own_grad = torch.zeros(R, self.d)
         self.own_grad1 = torch.zeros(R)
         for s in range(self.spec.N):
             for f in range(self.F):
-                k0, r0 = self._key_slot(s, f), self.bk.boff[f]
+                k0, r0 = self._key_slot(s, f), s * S + self.bk.boff[f]
                 n = int(recv_idx[s, k0])
                 li = recv_idx[s, k0 + 1:k0 + 1 + n] + self.local_off[f]
-                if grads is not None:
-                    self.own_grad.index_add_(0, li, grads[s, r0:r0 + n])
-                if grads1 is not None:
-                    self.own_grad1.index_add_(0, li, grads1[s, r0:r0 + n])
+                if self.with_emb:
+                    self.own_grad.index_add_(0, li, gbuf[r0:r0 + n, :self.d])
+                if self.with_lr:
+                    self.own_grad1.index_add_(0, li, gbuf[r0:r0 + n, self.lr_col])
         partials.zero_()
         partials[0] = (self.own_grad ** 2).sum() + (self.own_grad1 ** 2).sum()
 

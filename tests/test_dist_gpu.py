@@ -31,13 +31,14 @@ def single_gpu_reference(kind, optimizer, world, generic=False):
     return m, losses
 
 
-@pytest.mark.parametrize("kind,optimizer,graph", [("deepfm", "SGD", False), ("deepfm", "Adam", False), ("fm", "Adagrad", False),
-                                                  ("lr", "AdamW", False), ("dnn", "Adam", False),
-                                                  ("deepfm", "Adam", True), ("fm", "SGD", True)])
-def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, graph, tmp_path):
-    """graph=True: the step is replayed as HIP-graph segments with the collectives issued between them."""
+@pytest.mark.parametrize("kind,optimizer,extra", [("deepfm", "SGD", ""), ("deepfm", "Adam", ""), ("fm", "Adagrad", ""),
+                                                  ("lr", "AdamW", ""), ("dnn", "Adam", ""),
+                                                  ("deepfm", "Adam", "onestream"), ("fm", "SGD", "onestream")])
+def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
+    """Default: the dense all-reduce on a second stream and communicator beside the gradient exchange; onestream:
+    everything on one stream (the dense gradient's norm partials then ride in the owner's reduction)."""
     world = 2
-    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer] + (["graph"] if graph else []), timeout=200)
+    codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer] + ([extra] if extra else []), timeout=200)
     assert codes == [0] * world, "\n".join(outs)
     got = np.load(tmp_path / "state.npz")
     m, losses = single_gpu_reference(kind, optimizer, world)
@@ -68,7 +69,7 @@ def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tm
 
 
 @pytest.mark.parametrize("kind,optimizer,extra", [("deepfm", "Adam", "replicated"), ("fm", "SGD", "replicated"),
-                                                  ("lr", "AdamW", "replicated"), ("deepfm", "Adagrad", "replicated_graph")])
+                                                  ("lr", "AdamW", "replicated"), ("deepfm", "Adagrad", "replicated")])
 def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
     """ReplicatedTablesTrainer: every rank keeps whole tables and merges the all-gathered (row, gradient) pairs."""
     world = 2
@@ -82,6 +83,30 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
         if not v.dtype.is_floating_point:
             continue
         torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("kind,optimizer", [("deepfm", "Adam"), ("deepfm", "SGD"), ("fm", "AdamW"), ("lr", "Adagrad"),
+                                            ("dnn", "Adam")])
+def test_one_rank_rccl_graph_matches_eager(kind, optimizer, tmp_path):
+    """The real RCCL calls on a one-rank group: the step issued eagerly, the whole step as ONE HIP graph with the
+    collectives captured inside, and that graph with the dense all-reduce on the second stream and communicator -- the
+    same losses and weights bit for bit -- and all of them against the single-GPU fused step."""
+    codes, outs = run_ranks(1, ["gpu1", str(tmp_path), kind, optimizer], timeout=200)
+    assert codes == [0], "\n".join(outs)
+    ref = np.load(tmp_path / "state_eager.npz")
+    for name in ("graph", "graph_overlap", "replicated_graph"):
+        got = np.load(tmp_path / f"state_{name}.npz")
+        assert sorted(got.files) == sorted(ref.files)
+        for k in ref.files:
+            if name.startswith("replicated"):      # another way to the same sums
+                np.testing.assert_allclose(got[k], ref[k], rtol=2e-4, atol=2e-6, err_msg=f"{name}: {k}")
+            else:
+                assert np.array_equal(got[k], ref[k]), f"{name}: {k}"
+    m, losses = single_gpu_reference(kind, optimizer, 1)
+    np.testing.assert_allclose(ref["__losses__"], np.array(losses), rtol=2e-5)
+    for k, v in m.state_dict().items():
+        if v.dtype.is_floating_point:
+            torch.testing.assert_close(torch.from_numpy(ref[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
 
 
 @pytest.mark.parametrize("extra", [["--force-dist", "1"], ["--gpus", "2", "--rehearse-on-one-gpu", "1"]])
