@@ -64,11 +64,13 @@ def parse():
     p.add_argument("--distinct-batches", type=int, default=0,
                    help="resident synthetic batches the steps cycle through; 0 (default) = warmup + steps, i.e. no batch "
                         "is seen twice, so every step meets rows that are as stale as a first pass over the data makes them")
-    p.add_argument("--ahead", type=int, default=0,
-                   help="1 = announce every next batch to the step before it (step_tensors(..., next_idx=...)): its index "
-                        "sort rides in two backward GEMM launches and its Adam catch-up beside the update, as a feeder that "
-                        "stages batches ahead allows; 0 (default, measured faster: beside GEMM workgroups the sort runs "
-                        "three to five times as long as alone) = every step prepares its own batch in front of its lookup")
+    p.add_argument("--ahead", type=int, default=-1,
+                   help="1 = announce every next batch to the step before it (step_tensors(..., next_idx=...)), as a feeder "
+                        "that stages batches ahead allows; 0 = every step prepares its own batch in front of its lookup.  "
+                        "Several GPUs (default 1): the key exchange of the next batch -- sort, bucketing, all-to-all -- runs "
+                        "on the second stream beside the step.  One GPU (default 0, measured faster): the index sort rides "
+                        "in two backward GEMM launches -- where it runs three to five times as long as alone -- and the Adam "
+                        "catch-up beside the update")
     p.add_argument("--force-dist", type=int, default=0,
                    help="N=1 only: run the row-sharded multi-GPU trainer with a one-rank RCCL group (what the sharded "
                         "path costs on top of the single-GPU step, and a check of the RCCL calls on one GPU)")
@@ -77,8 +79,8 @@ def parse():
                         "0 = issued eagerly (host-bound: about thirty entry-point calls and five collectives per step)")
     p.add_argument("--overlap-comm", type=int, default=-1,
                    help="sharded tables: all-reduce of the dense gradient on a second stream and communicator beside the "
-                        "gradient all-to-all and the owner-side reduction (0: everything on one stream; default: with more "
-                        "than one rank)")
+                        "gradient all-to-all and the owner-side reduction, and the key exchange of the next batch on a "
+                        "third (default); 0: everything on one stream")
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
@@ -167,6 +169,41 @@ def cpu_baseline(args, rec, hidden, idx_cpu, lab_cpu):
     return {"value": n * args.batch / el, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of batch {args.batch} after {n_warm} warm-up steps, same synthetic batches, "
                       f"torch CPU ops with {cores} threads ({el:.1f} s)"}
+
+
+class _TwoSlotFeeder:
+    """Batch i is served from input buffer pair i % 2; a side stream copies batch i + 2 into the pair as soon as step i
+    is through with it, i.e. while step i + 1 runs -- the device-side picture of a feeder that stages batches ahead.
+    With a trainer that exchanges the keys of an announced batch on a stream of its own (`stream`), the copies go
+    through that stream: the key exchange of batch i + 1 then follows its copy in stream order, and the step, which
+    waits for the key exchange, needs no event of the feeder's."""
+
+    def __init__(self, idxs, labs, device, stream=None):
+        self.idxs, self.labs = idxs, labs
+        self.n = len(idxs)
+        self.buf = [(idxs[k % self.n].clone(), labs[k % self.n].clone()) for k in range(2)]
+        self.shared = stream is not None
+        self.side = stream if stream is not None else torch.cuda.Stream(device=device)
+        self.filled = [None, None]          # event: the copy into pair k has finished
+
+    def take(self, i):
+        k = i % 2
+        if not self.shared and self.filled[k] is not None:
+            torch.cuda.current_stream().wait_event(self.filled[k])
+        return self.buf[k][0], self.buf[k][1], self.buf[(i + 1) % 2][0]
+
+    def done(self, i):
+        """Step i has been issued: refill its buffer pair with batch i + 2 once it has run."""
+        k = i % 2
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.buf[k][0].copy_(self.idxs[(i + 2) % self.n])
+            self.buf[k][1].copy_(self.labs[(i + 2) % self.n])
+            if not self.shared:
+                self.filled[k] = torch.cuda.Event()
+                self.filled[k].record()
 
 
 def self_launch(args):
@@ -280,31 +317,55 @@ def main():
     # The pre-staged batches stay resident: with --graph one graph per batch buffer, replayed without copies.  The
     # graphs are captured first (capturing leaves the training state as it was), so that the W warm-up steps and the K
     # timed steps walk through W + K different batches when that many are resident (the default).
-    use_next = bool(args.ahead) and hasattr(eng, "_ahead_supported") and eng._ahead_supported(args.batch)
+    use_next = args.ahead == 1 and hasattr(eng, "_ahead_supported") and eng._ahead_supported(args.batch)
 
     def announce(i):
         return {"next_idx": idx_dev[(i + 1) % nb]} if use_next else {}
 
-    # Several GPUs: ONE graph (RCCL collectives inside), every batch copied into its input buffers first -- what a
-    # feeder's one host-to-device copy per step does.
-    resident = not use_dist
-    if eng.use_graph and hasattr(eng, "prepare") and resident:
-        for i in range(args.warmup + args.steps):
-            kw = dict(announce(i), ahead_slot=(i % 2) if i > 0 else None) if use_next else {}
-            eng.prepare(idx_dev[i % nb], lab_dev[i % nb], **kw)
+    feeder = None
+    if use_dist:
+        # Several GPUs: the step reads its batch from one of TWO input buffer pairs, which a side stream fills one step
+        # ahead (what a feeder's host-to-device copy does while the step before runs): two graphs with the RCCL
+        # collectives inside instead of one per batch, and the step can be told its next batch (--ahead).
+        use_next = args.ahead != 0 and getattr(eng, "_ahead_kind", "") == "keys" and eng._ahead_supported(args.batch)
+        feeder = _TwoSlotFeeder(idx_dev, lab_dev, device, stream=eng.side_keys if (use_next and eng.use_graph) else None)
+
+        def run_step(i):
+            idx, lab, nxt = feeder.take(i)
+            kw = {"next_idx": nxt} if use_next else {}
+            out = eng.step_tensors(idx, lab, resident=True, **kw) if hasattr(eng, "_graph_key") else eng.step_tensors(idx, lab)
+            feeder.done(i)
+            return out
+    else:
+        def run_step(i):
+            return eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=True, **announce(i))
+        if eng.use_graph and hasattr(eng, "prepare"):
+            for i in range(args.warmup + args.steps):
+                kw = dict(announce(i), ahead_slot=(i % 2) if i > 0 else None) if use_next else {}
+                eng.prepare(idx_dev[i % nb], lab_dev[i % nb], **kw)
     for i in range(args.warmup):
-        eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=resident, **announce(i))
+        run_step(i)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
 
+    step_events = [] if os.environ.get("RS_BENCH_STEP_TIMES") else None      # diagnostic: GPU time of every timed step
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        loss = eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb], resident=resident, **announce(i))
+        loss = run_step(i)
+        if step_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append((ev, time.perf_counter() - t0))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if step_events:
+        gpu = [round(a[0].elapsed_time(b[0]) * 1e3) for a, b in zip(step_events, step_events[1:])]
+        host = [round((b[1] - a[1]) * 1e6) for a, b in zip(step_events, step_events[1:])]
+        print("step GPU us:", gpu, file=sys.stderr)
+        print("step host issue us:", host, file=sys.stderr)
 
     # Per-launch durations: the same K steps issued eagerly with a HIP event pair around every launch, on the
     # launch stream.  A spin kernel in front of every step keeps the GPU busy while the host enqueues the step, so
@@ -492,7 +553,7 @@ def main():
         import gc
         import torch.distributed as dist
         # graphs that captured collectives go before the communicator does
-        getattr(eng, "_graphs", {}).clear()
+        eng.release_graphs() if hasattr(eng, "release_graphs") else getattr(eng, "_graphs", {}).clear()
         gc.collect()
         torch.cuda.synchronize()
         dist.destroy_process_group()

@@ -385,9 +385,10 @@ class ShardedExchange:
         self.g_r = z((N * S, W))
 
     # ---- forward, in the three pieces a trainer may interleave with other work -----------------------------
-    def send_keys(self, idx):
-        """Requester: sort + de-duplicate the batch, bucket its distinct keys by owner, exchange them."""
-        k, c = self.k, self.comm
+    def send_keys(self, idx, comm: Optional[Comm] = None):
+        """Requester: sort + de-duplicate the batch, bucket its distinct keys by owner, exchange them (comm: another
+        communicator than the exchange's own, for a key exchange that runs beside the step before)."""
+        k, c = self.k, comm or self.comm
         k.sort_batch(idx)
         k.route(self.send_idx, self.route, self.overflow)
         c.all_to_all(self.recv_idx, self.send_idx)
@@ -438,7 +439,7 @@ class ShardedExchange:
                           "raise bucket_slack")
 
 
-def _capture_with_collectives(trainer, idx, labels):
+def _capture_with_collectives(trainer, idx, labels, next_idx=None, entry=None, run_prologue=False):
     """FusedTrainer._capture for a step with RCCL collectives inside.  The warm-up steps (and the first replay) run for
     real -- collectives included, on every rank -- and are undone.  Other threads of the process group (its watchdog)
     keep working during capture, hence the thread-local capture mode; the watchdog is given time to retire the
@@ -448,7 +449,7 @@ def _capture_with_collectives(trainer, idx, labels):
     trainer._capture_error_mode = "thread_local"
     torch.cuda.synchronize()
     time.sleep(0.5)
-    return FusedTrainer._capture(trainer, idx, labels)
+    return FusedTrainer._capture(trainer, idx, labels, next_idx, entry, run_prologue)
 
 
 def _reject_batchnorm(model, who: str):
@@ -465,6 +466,10 @@ def _reject_batchnorm(model, who: str):
 # -------------------------------------------------------------------------------------------------
 class DistributedTrainer(FusedTrainer):
     """FusedTrainer with row-sharded tables and a data-parallel dense tower (see the module docstring).
+
+    step_tensors(..., next_idx=...) (the batch of the next call, see FusedTrainer.step_tensors): the key exchange of
+    that batch -- its sort, the bucketing of its distinct keys, their all-to-all, the owners' list lengths -- runs on the
+    second stream and communicator beside this step's GEMMs, and the next step starts with the owners serving rows.
 
     Every rank must build the same model from the same seed before constructing the trainer; the
     trainer keeps only this rank's shard of each table as training state.  ``sync_to_model()``
@@ -494,13 +499,22 @@ class DistributedTrainer(FusedTrainer):
         self._update_shares_launch = True
         self._reduce_carries_finishes = True
         # the all-reduce of the dense gradient on a stream and a communicator of its own, beside the gradient exchange
-        # (default: with more than one rank -- alone, a rank's all-reduce is a copy and there is nothing to hide)
-        self.overlap_comm = self.world > 1 if overlap_comm is None else bool(overlap_comm)
+        # (the same streams carry the key exchange of an announced next batch, see step_tensors)
+        self.overlap_comm = True if overlap_comm is None else bool(overlap_comm)
         self.comm_dense = self.comm.second() if self.overlap_comm else self.comm
         self.side_comm = torch.cuda.Stream(device=self.device) if self.overlap_comm else None
         self.ws_comm = ops.Workspace(self.device)
-        # a bucket that overflows serves zeros for the keys it lost: look at the flag often
-        self.check_every = 16
+        # the key exchange of an announced next batch: a stream of its own, forked once and joined once per step
+        # (and a communicator of its own: one communicator per stream)
+        self.side_keys = torch.cuda.Stream(device=self.device) if self.overlap_comm else None
+        self.comm_keys = self.comm.second() if self.overlap_comm else self.comm
+        self.ws_keys = ops.Workspace(self.device)
+        self._keys_in_flight = False
+        self._key_graphs = {}
+        self._keys_event = None
+        # a bucket that overflows serves zeros for the keys it lost: look at the flags often (they are read without a
+        # host synchronisation and reported one to two polls later, i.e. within 16 steps)
+        self.check_every = 8
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments
@@ -527,8 +541,19 @@ class DistributedTrainer(FusedTrainer):
         # the dense tower must start identical on every rank
         self.comm.broadcast(self.flat_w, 0)
 
-    def exchange(self, B: int) -> ShardedExchange:
-        if B not in self._ex:
+    _ahead_kind = "keys"
+
+    def _ahead_supported(self, B: int) -> bool:
+        return self.overlap_comm             # the key exchange of the next batch needs the second stream and communicator
+
+    def _run_prologue(self, idx, entry):
+        self.exchange(entry["B"], entry["slot"]).send_keys(idx)
+
+    def exchange(self, B: int, slot: int = 0) -> ShardedExchange:
+        """Buffers and plans of the exchange for batches of B samples; two slots, so that the keys of the next batch
+        can be exchanged while this one's are still needed by its backward pass."""
+        key = (B, slot)
+        if key not in self._ex:
             bk = self.spec.buckets(B, slack=self.bucket_slack, device=self.device)
             k = HipShardKernels(self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
             ex = ShardedExchange(k, self.comm, self.spec, B, self.d, self.has_emb, self.has_lr, bk, self.device)
@@ -537,8 +562,8 @@ class DistributedTrainer(FusedTrainer):
             ex.norm_buf = torch.zeros(k.n_own_partials + N_DENSE_PARTIALS, dtype=torch.float32, device=self.device)
             ex.own_partials = ex.norm_buf[:k.n_own_partials]
             ex.dense_partials = ex.norm_buf[k.n_own_partials:]
-            self._ex[B] = ex
-        return self._ex[B]
+            self._ex[key] = ex
+        return self._ex[key]
 
     # ---- hooks -----------------------------------------------------------------------------------
     def _grad_scale(self) -> float:
@@ -557,15 +582,24 @@ class DistributedTrainer(FusedTrainer):
 
     def _embed_forward(self, idx):
         """K1 through the exchange: distinct keys out, rows back, then the fused lookup in the received rows."""
-        ex = self.exchange(idx.shape[1])
-        ex.send_keys(idx)
+        c, B = self._step_ctx, idx.shape[1]
+        ex = self._cur_ex = self.exchange(B, c["slot"])
+        if not c["done_ahead"]:
+            ex.send_keys(idx)
+        if c["next_idx"] is not None:
+            # the key exchange of the next batch, beside this step: second stream, second communicator, the other slot
+            nxt = self.exchange(B, 1 - c["slot"])
+            self.side_keys.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side_keys), ops.use_workspace(self.ws_keys):
+                nxt.send_keys(c["next_idx"], comm=self.comm_keys)
+            self._keys_in_flight = True
         ex.serve_rows(self.shard, self.shard1, rs=self.rs_shard, rs1=self.rs_shard1)
         return ex.k.lookup(ex.pay_r, self.lrm.bias.data if self.has_lr else None, want_emb=self.has_emb,
                            want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
 
     def _embed_backward(self, plan, idx, gout, dz, ctx, sorted_already, dense_partials=None, colsum=None, splitk=None):
         B = idx.shape[1]
-        ex = self.exchange(B)
+        ex = self._cur_ex
         ex.reduce_local(gout, dz if self.has_fm else None, ctx["S"],
                         ctx["emb"].view(B * self.F, self.d) if self.has_fm else None, dz if self.has_lr else None,
                         colsum=colsum, splitk=splitk)
@@ -578,13 +612,15 @@ class DistributedTrainer(FusedTrainer):
             ex.send_grads(ex.own_partials)
             self.comm.all_reduce(ex.own_partials)
             main.wait_stream(self.side_comm)
+            if self._keys_in_flight:
+                main.wait_stream(self.side_keys)
+                self._keys_in_flight = False
         else:
             # one stream: the dense gradient is summed over ranks in front of the owner's reduction, whose second
             # launch then also leaves its norm partials
             ex.send_grads(ex.own_partials, before_merge=lambda: self._dense_grad_norm(ex, sumsq=False),
                           dense=self.flat_g, dense_partials=ex.dense_partials)
             self.comm.all_reduce(ex.own_partials)
-        self._cur_ex = ex
 
     def _dense_grad_norm(self, ex, sumsq=True):
         """Sum the flat dense gradient over ranks; its L2 term; its sum-of-squares partials."""
@@ -599,7 +635,7 @@ class DistributedTrainer(FusedTrainer):
 
     def _embed_update(self, plan, with_dense=False, stamps=True, next_plan=None):
         # `plan` is the base class's per-batch-size plan; the update runs on the owner-side plan of the exchange
-        ex = self._ex[plan.cap]
+        ex = self._cur_ex
         ex.k.update(self.opt, self.hyper, self.scal, self.shard, self.shard_m, self.shard_v, self.shard1,
                     self.shard1_m, self.shard1_v,
                     dense=(self.flat_w, self.flat_g, self.flat_m, self.flat_v) if with_dense else None,
@@ -607,7 +643,47 @@ class DistributedTrainer(FusedTrainer):
 
     # ---- the whole step as one HIP graph, collectives inside --------------------------------------------
     def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
-        return _capture_with_collectives(self, idx, labels)
+        return _capture_with_collectives(self, idx, labels, next_idx, entry, run_prologue)
+
+    def step_tensors(self, idx, labels, resident: bool = False, next_idx=None):
+        """FusedTrainer.step_tensors.  With use_graph, an announced next batch gets a HIP graph of its own for its key
+        exchange, replayed on the key stream beside the step's graph (forking a captured step into the key stream early
+        and joining it late makes hipStreamEndCapture crash on ROCm 7.0)."""
+        if self._keys_event is not None:                 # the keys this step may start from have arrived
+            torch.cuda.current_stream().wait_event(self._keys_event)
+            self._keys_event = None
+        B = idx.shape[1]
+        if not (self.use_graph and resident and next_idx is not None and self._ahead_supported(B)
+                and tuple(next_idx.shape) == tuple(idx.shape) and next_idx.dtype == torch.int64 and next_idx.is_contiguous()):
+            return FusedTrainer.step_tensors(self, idx, labels, resident=resident, next_idx=next_idx)
+        slot = self._ahead_slot_for(idx)
+        cur = slot if slot is not None else 0
+        self._keys_graph(next_idx, 1 - cur)
+        loss = FusedTrainer.step_tensors(self, idx, labels, resident=True, next_idx=None)
+        self._ahead = {"key": self._tensor_key(next_idx), "slot": 1 - cur, "B": B, "marked": False}
+        return loss
+
+    def _keys_graph(self, next_idx, slot):
+        """send_keys of the announced batch into exchange slot `slot`, on the key stream, from a graph of its own."""
+        import time
+        ex = self.exchange(next_idx.shape[1], slot)
+        side = self.side_keys
+        side.wait_stream(torch.cuda.current_stream())    # the step that last used this slot's buffers has been issued
+        key = (next_idx.data_ptr(), tuple(next_idx.shape), slot)
+        with torch.cuda.stream(side), ops.use_workspace(self.ws_keys):
+            g = self._key_graphs.get(key)
+            if g is None:
+                ex.send_keys(next_idx, comm=self.comm_keys)          # for real (and the kernels' first launch)
+                torch.cuda.synchronize()
+                time.sleep(0.5)                                       # see _capture_with_collectives
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    ex.send_keys(next_idx, comm=self.comm_keys)
+                self._key_graphs[key] = g
+            else:
+                g.replay()
+            self._keys_event = torch.cuda.Event()
+            self._keys_event.record(side)
 
     def _mutable_state(self):
         ts = super()._mutable_state()
@@ -638,9 +714,17 @@ class DistributedTrainer(FusedTrainer):
         pad[:shard.shape[0]] = shard
         return [g[:k] for g, k in zip(self.comm.all_gather(pad), ns)]
 
+    def _flag_tensors(self):
+        out = []
+        for ex in self._ex.values():
+            out += [(ex.overflow, "bucket overflow"), (ex.k.layout_own.err_flag, "index (owner)"),
+                    (ex.k.layout_req.err_flag, "index (requester)")]
+        return out           # (the merge's capacity marker, which the bucket sizes rule out, is left to check())
+
     def check(self):
         """Bucket overflow of the exchange (rows would be served as zeros and their gradients dropped) and index range:
-        raise.  Runs every check_every steps and before sync_to_model()."""
+        raise.  Synchronous; every check_every steps the flags are polled without synchronisation (_poll_flags), and this
+        runs when a poll finds one raised, and before sync_to_model()."""
         self._unchecked = 0
         for ex in self._ex.values():
             ex.check_overflow()

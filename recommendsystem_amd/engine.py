@@ -63,6 +63,10 @@ class _Fork:
 
 
 class FusedTrainer:
+    # what a step does for the batch announced with next_idx: "plan" = its index sort and Adam catch-up (this class);
+    # subclasses with row-sharded tables exchange its keys instead ("keys")
+    _ahead_kind = "plan"
+
     def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
                  optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = False,
                  exact_adam: bool = True):
@@ -149,8 +153,10 @@ class FusedTrainer:
         self.last = {}
         # device-side error flags (index out of range; on several GPUs also bucket overflow of the exchange) are read
         # every check_every steps -- a host synchronisation -- and by check() before tables are read as a whole
-        self.check_every = 256
+        self.check_every = 128
         self._unchecked = 0
+        self._watch = None
+        self._first_poll = True          # the first step polls too: the one-time cost of the poll's own kernels falls there
         # Work of the NEXT batch done inside a step (step_tensors(..., next_idx=...)): which tensor it was done for and
         # which of the two plans holds its sort.  None: the next step does that work itself, in front of its lookup.
         self._ahead = None
@@ -244,6 +250,19 @@ class FusedTrainer:
         raises at once; the kernels clamp such indices to the padding row and set a flag).  Device sync."""
         self._unchecked = 0
         self.layout.check_indices()
+
+    def _flag_tensors(self):
+        """(device flag, what it means) pairs that check() would look at."""
+        return [(self.layout.err_flag, "index")]
+
+    def _poll_flags(self):
+        """The periodic form of check(): no host synchronisation (ops.FlagWatch) -- a raised flag is reported by the
+        synchronous check() one to two polling intervals after the step that raised it."""
+        self._unchecked = 0
+        if self._watch is None:
+            self._watch = ops.FlagWatch(self.device)
+        if self._watch.poll(self._flag_tensors()):
+            self.check()
 
     def _check_tables(self):
         for tab, ver in self._versions:
@@ -471,23 +490,26 @@ class FusedTrainer:
         self._ahead = None
         do_ahead = (next_idx is not None and self._ahead_supported(B) and tuple(next_idx.shape) == tuple(idx.shape)
                     and next_idx.dtype == torch.int64 and next_idx.is_contiguous())
-        plan = self.plan(B, slot)
-        next_plan = self.plan(B, 1 - slot) if do_ahead else None
+        plan_mode = self._ahead_kind == "plan"
+        plan = self.plan(B, slot if plan_mode else 0)
+        next_plan = self.plan(B, 1 - slot) if (do_ahead and plan_mode) else None
+        # what the embedding hooks of subclasses need to know about this step
+        self._step_ctx = {"slot": slot, "done_ahead": done_ahead, "next_idx": next_idx if do_ahead else None}
         # exact Adam with work done ahead: a batch's rows are stamped "stepped" before its update (catchup_plan), and
         # the update writes no stamps
-        promised = self.exact and (done_ahead or do_ahead)
+        promised = plan_mode and self.exact and (done_ahead or do_ahead)
         main = torch.cuda.current_stream()
         overlap = self.overlap == 1
         keep = []                    # intermediates read on side streams stay alive until the join
         # The index sort needs only the batch: it runs beside the forward pass.
-        fork_sort = bool(self.overlap) and self._sort_can_fork and not done_ahead
+        fork_sort = bool(self.overlap) and self._sort_can_fork and not (done_ahead and plan_mode)
         if fork_sort:
             with self._fork(self.side_sort, self.ws_sort):
                 plan.sort_columnar(idx)
         head_fast = bool(self.blocks) and self._head_fast
         # single GPU, one stream: the sort shares the gather's launch (it keeps only F workgroups busy)
         sort_early = self._fuse_small and not fork_sort
-        if done_ahead:
+        if done_ahead and plan_mode:
             parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan="done")
         elif promised:
             # first step of a run that announces its batches: sort, then replay + promise per distinct row, then look up
@@ -497,8 +519,8 @@ class FusedTrainer:
         else:
             # the update at the end of the step stamps the rows it steps, so the catch-up does not mark ahead
             parts, ctx = self.forward_parts(idx, defer_head=head_fast, sort_plan=plan if sort_early else None)
-        sorted_already = fork_sort or sort_early or done_ahead or promised
-        ahead_sort_pending = do_ahead        # the next batch's sort still has to be issued
+        sorted_already = fork_sort or sort_early or (plan_mode and done_ahead) or promised
+        ahead_sort_pending = do_ahead and plan_mode      # the next batch's sort still has to be issued
         ahead_sort_half = False              # ... its first half has been
         lastb = self.blocks[-1] if self.blocks else None
         # partial column sums -> one finishing launch (bias gradients; with a fused head also the loss and its batch sums)
@@ -714,7 +736,7 @@ class FusedTrainer:
                 ops.dense_update(t["w"].view(-1), t["g"].view(-1), t["m"].view(-1) if t["m"] is not None else None,
                                  t["v"].view(-1) if t["v"] is not None else None, self.opt, self.hyper, self.scal)
         if do_ahead:
-            self._ahead = {"key": self._tensor_key(next_idx), "slot": 1 - slot, "B": B, "marked": self.exact}
+            self._ahead = {"key": self._tensor_key(next_idx), "slot": 1 - slot, "B": B, "marked": self.exact and plan_mode}
         self.last = {"dz": dz, "parts": parts}
         del keep
         return loss
@@ -760,8 +782,9 @@ class FusedTrainer:
         is not kept costs one small launch (the rows' stamps are taken back); results do not depend on next_idx."""
         self._check_tables()
         self._unchecked += 1
-        if self.check_every and self._unchecked >= self.check_every:
-            self.check()
+        if self.check_every and (self._unchecked >= self.check_every or self._first_poll):
+            self._first_poll = False
+            self._poll_flags()
         if self._ahead is not None and self._ahead_slot_for(idx) is None:
             self._cancel_ahead()
         if not self.use_graph:
@@ -804,12 +827,25 @@ class FusedTrainer:
             return
         entry = None
         if ahead_slot is not None and self._ahead_supported(idx.shape[1]):
-            entry = {"key": self._tensor_key(idx), "slot": int(ahead_slot), "B": idx.shape[1], "marked": self.exact}
+            entry = {"key": self._tensor_key(idx), "slot": int(ahead_slot), "B": idx.shape[1],
+                     "marked": self.exact and self._ahead_kind == "plan"}
         key = self._graph_key(idx, labels, next_idx, entry)
         if key not in self._graphs:
             saved = self._ahead
             self._graphs[key] = self._capture(idx, labels, next_idx, entry, run_prologue=entry is not None)
             self._ahead = saved
+
+    def release_graphs(self):
+        """Drop every captured graph (graphs that captured collectives must go before their communicator does)."""
+        self._graphs.clear()
+        getattr(self, "_key_graphs", {}).clear()
+
+    def _run_prologue(self, idx, entry):
+        """What the step before would have done for `idx` had it been announced (entry: the record it would have left)."""
+        p = self.plan(entry["B"], entry["slot"])
+        p.sort_columnar(idx)
+        if entry["marked"]:
+            p.catchup_plan(*self._row_states(), mode=0)
 
     def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
         """Capture one step reading `idx`/`labels` in place; the model state is left untouched.  entry: the record of
@@ -822,10 +858,7 @@ class FusedTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), ops.use_workspace(self.ws):
             if run_prologue:
-                p = self.plan(entry["B"], entry["slot"])
-                p.sort_columnar(idx)
-                if entry["marked"]:
-                    p.catchup_plan(*self._row_states(), mode=0)
+                self._run_prologue(idx, entry)
             for _ in range(2):
                 self._ahead = dict(entry) if entry else None
                 self._step_impl(idx, labels, next_idx)

@@ -67,6 +67,38 @@ class FieldLayout:
             raise IndexError("index out of range in embedding lookup")
 
 
+class FlagWatch:
+    """Device-side error flags read without stopping the step stream: poll() looks at the copy it requested the time
+    before (long since arrived in pinned host memory) and requests a new one.  A flag that is raised is therefore
+    reported between one and two polls later; check() of the owner remains the synchronous form."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._host = None
+        self._event = None
+
+    def poll(self, flags):
+        """flags: list of (1-element int32 device tensor, nonzero -> name); returns the names found raised in the
+        PREVIOUS snapshot (empty list if there was none yet), and requests a snapshot of the current values."""
+        raised = []
+        if self._event is not None:
+            self._event.synchronize()             # recorded a whole poll interval ago: returns at once
+            vals = self._host.tolist()
+            raised = [name for (t, name), v in zip(self._names, vals) if v != 0]
+        n = len(flags)
+        if n == 0:
+            self._event = None
+            return raised
+        if self._host is None or self._host.numel() != n:
+            self._host = torch.zeros(n, dtype=torch.int32).pin_memory()
+        snap = torch.cat([t.view(1) for t, _ in flags])
+        self._host.copy_(snap, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._names = list(flags)
+        return raised
+
+
 def gather_fwd(idx: torch.Tensor, layout: FieldLayout, table: torch.Tensor) -> torch.Tensor:
     """out[b, f, :] = table[row_offset[f] + idx[f, b], :]; idx is [F, B] int64."""
     Fn, B = idx.shape

@@ -89,12 +89,13 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
                                             ("dnn", "Adam")])
 def test_one_rank_rccl_graph_matches_eager(kind, optimizer, tmp_path):
     """The real RCCL calls on a one-rank group: the step issued eagerly, the whole step as ONE HIP graph with the
-    collectives captured inside, and that graph with the dense all-reduce on the second stream and communicator -- the
-    same losses and weights bit for bit -- and all of them against the single-GPU fused step."""
+    collectives captured inside, that graph with the dense all-reduce on the second stream and communicator, and (eagerly
+    and from graphs) with every next batch announced, whose key exchange then runs on that second stream -- the same
+    losses and weights bit for bit -- and all of them against the single-GPU fused step."""
     codes, outs = run_ranks(1, ["gpu1", str(tmp_path), kind, optimizer], timeout=200)
     assert codes == [0], "\n".join(outs)
     ref = np.load(tmp_path / "state_eager.npz")
-    for name in ("graph", "graph_overlap", "replicated_graph"):
+    for name in ("graph", "graph_overlap", "eager_ahead", "graph_ahead", "replicated_graph"):
         got = np.load(tmp_path / f"state_{name}.npz")
         assert sorted(got.files) == sorted(ref.files)
         for k in ref.files:
