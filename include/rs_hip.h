@@ -461,6 +461,9 @@ int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, i
  *   mode 0: every row of the plan whose stamp is below *step is brought up to *step steps, and all rows of the plan are
  *           stamped *step + 1; the update that follows is then given no stamps to write (last = last1 = NULL).
  *   mode 1: the promise is taken back (stamps above *step return to *step) when that update does not come.
+ *   mode 2: no promise -- rs_adam_catchup (mark_ahead = 0) once per distinct row instead of once per entry: rows below
+ *           *step are brought up to it and stamped *step (the owner side of the row-sharded exchange, whose merged plan
+ *           of the received key lists exists before the rows are served).
  * rs_sparse_dense_update_ahead is rs_sparse_dense_update (without stamps) with mode 0 for `next_plan`, the sorted plan
  * of the batch the NEXT step trains on, in the same launch: the rows `plan` steps carry the stamp *step from the
  * promise made to this update, so the replay leaves them alone, and every other row of the next batch is not touched

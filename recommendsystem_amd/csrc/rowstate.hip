@@ -28,7 +28,7 @@ __global__ __launch_bounds__(CT) void adam_catchup_kernel(CatchArgs a, int per_t
     catchup_block<CT>(a, blockIdx.x, per_table);
 }
 
-// the distinct rows of a sorted batch (rowstate_body.h, catchup_seg_block); grid (ceil(cap / rows per block), F)
+// the distinct rows of a sorted batch (rowstate_body.h, catchup_seg_block); grid (seg_catchup_blocks(), F)
 template <int VEC>
 __global__ __launch_bounds__(CT) void adam_catchup_plan_kernel(SegCatchArgs a) {
     catchup_seg_block<VEC, CT>(a, blockIdx.y, blockIdx.x);
@@ -115,20 +115,22 @@ int rs_adam_catchup_lists(const int64_t* keys, const int* sub_off, const int* su
 // The replay for the distinct rows of a sorted batch (`plan`: rs_sparse_bwd_sort's, F fields of capacity cap), with the
 // rows promised to the next update: mode 0 brings every row of the plan whose stamp is below *step up to *step and
 // stamps all of them *step + 1 (the update that follows must then be given no stamps); mode 1 takes the promise back
-// (stamps above *step return to *step) when that update does not come.  No atomics: a plan names a row once.
+// (stamps above *step return to *step) when that update does not come; mode 2 is rs_adam_catchup per distinct row
+// (rows below *step brought up to it and stamped *step; the update that follows stamps as usual).  No atomics: a plan
+// names a row once.
 int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
                          float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
                          const float* bctab, int tab_n, int kmax, int mode, hipStream_t stream) {
     RS_CHECK_ARG(plan && step && hyper, "rs_adam_catchup_plan: null pointer");
     RS_CHECK_ARG(opt == RS_OPT_ADAM || opt == RS_OPT_ADAMW, "rs_adam_catchup_plan: optimizer %d has nothing to replay", opt);
     RS_CHECK_ARG(F > 0 && cap > 0 && kmax >= 0 && tab_n >= 0 && (tab_n == 0 || bctab), "rs_adam_catchup_plan: bad sizes");
-    RS_CHECK_ARG(mode == 0 || mode == 1, "rs_adam_catchup_plan: mode must be 0 or 1");
+    RS_CHECK_ARG(mode >= 0 && mode <= 2, "rs_adam_catchup_plan: mode must be 0, 1 or 2");
     const PlanView pv = carve_plan(const_cast<int*>(plan), F, cap);
     SegCatchArgs a{};
     const int nt = fill_seg_catchup(a, pv.seg_row, pv.counts, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step,
                                     hyper, bctab, tab_n, kmax, mode);
     RS_CHECK_ARG(nt > 0, "rs_adam_catchup_plan: no table, or a table without m / v / last, or a row width the kernels do not take (%d)", d);
-    const dim3 grid(rs_cdiv(cap, seg_rows_per_block(a.t[0].d, CT)), F);
+    const dim3 grid(seg_catchup_blocks(a, CT), F);
     if (a.t[0].d % 4 == 0) hipLaunchKernelGGL(adam_catchup_plan_kernel<4>, grid, dim3(CT), 0, stream, a);
     else hipLaunchKernelGGL(adam_catchup_plan_kernel<1>, grid, dim3(CT), 0, stream, a);
     RS_CHECK_LAUNCH("rs_adam_catchup_plan");

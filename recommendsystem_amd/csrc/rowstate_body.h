@@ -202,28 +202,35 @@ __device__ __forceinline__ void catchup_block(const CatchArgs& a, int block, int
 //                    tells the catch-up after that one that the row is in good hands.  The update therefore leaves the
 //                    stamps alone in this mode, and runs beside this code without touching the same rows' moments.
 // mode 1 takes the promise back (last[row] > c -> c) when the batch the plan was made for does not come.
+// mode 2 is the plain replay for a plan whose rows the NEXT launches read and step with stamps of their own: rows
+// below c are brought up to c and stamped c (what rs_adam_catchup does per entry, here once per distinct row).
 struct SegCatchArgs {
     const int* seg_row; const int* counts;      // [F, cap] rows of the distinct keys, [F, 4] (n, chunks, segments, padding)
     int F, cap;
     RowTab t[2]; int nt;
+    int nb0;                                    // workgroups per field that serve t[0]; those behind them serve t[1]
     int opt; const long long* step;
     const float* hyper; const float* bctab; int tab_n; int kmax;
     int mode;
 };
 
-// rows a workgroup of NT threads serves: one per group of C lanes (C = lanes of a row of the first table)
-inline int seg_rows_per_block(int d0, int NT) {
-    const int C = d0 % 4 == 0 ? d0 / 4 : d0;
+// rows a workgroup of NT threads serves: one per group of C lanes (C = lanes of a row of width d)
+inline int seg_rows_per_block(int d, int NT) {
+    const int C = d % 4 == 0 ? d / 4 : d;
     return NT / C > 0 ? NT / C : 1;
 }
 
-// Workgroup bx of the ceil(cap / rows per block) that serve field f.  A group of C lanes per distinct row: every lane
-// reads the row's stamps, replays its slice of the first table (VEC floats; lane 0 of the group also the 1-dim second
-// table), lane 0 writes the new stamps.  The operands of both tables are requested before either is replayed.
+// workgroups per field of a launch that serves plans of `cap` slots; sets a.nb0
+inline int seg_catchup_blocks(SegCatchArgs& a, int NT) {
+    a.nb0 = (a.cap + seg_rows_per_block(a.t[0].d, NT) - 1) / seg_rows_per_block(a.t[0].d, NT);
+    return a.nb0 + (a.nt > 1 ? (a.cap + seg_rows_per_block(a.t[1].d, NT) - 1) / seg_rows_per_block(a.t[1].d, NT) : 0);
+}
+
+// One table: workgroup bx of the ceil(cap / rows per block) that serve field f.  A group of C lanes per distinct row:
+// every lane reads the row's stamp and replays its slice (VEC floats), lane 0 writes the new stamp.
 template <int VEC, int NT>
-__device__ __forceinline__ void catchup_seg_block(const SegCatchArgs& a, int f, int bx) {
-    const RowTab t0 = a.t[0];
-    const int C = t0.d / VEC;
+__device__ __forceinline__ void catchup_seg_table(const SegCatchArgs& a, const RowTab& t, int f, int bx) {
+    const int C = t.d / VEC;
     const int rpb = NT / C > 0 ? NT / C : 1;
     const int nseg = a.counts[f * 4 + 2];
     if (bx * rpb >= nseg) return;                                   // uniform over the workgroup
@@ -231,41 +238,34 @@ __device__ __forceinline__ void catchup_seg_block(const SegCatchArgs& a, int f, 
     const int u = bx * rpb + grp;
     const bool act = grp < rpb && u < nseg;
     const int c = (int)*a.step;
-    int row = 0, l0 = c, l1 = c;
+    int row = 0, l = c;
     if (act) {
         row = a.seg_row[(long long)f * a.cap + u];
-        l0 = t0.last[row];
-        if (a.nt > 1) l1 = a.t[1].last[row];
+        l = t.last[row];
     }
-    __syncthreads();                                                // every lane of a row has read its stamps before they change
+    __syncthreads();                                                // every lane of a row has read its stamp before it changes
     if (!act) return;
     if (a.mode == 1) {
-        if (cc == 0) {
-            if (l0 > c) t0.last[row] = c;
-            if (a.nt > 1 && l1 > c) a.t[1].last[row] = c;
-        }
+        if (cc == 0 && l > c) t.last[row] = c;
         return;
     }
-    const bool r0 = l0 < c, r1 = a.nt > 1 && cc == 0 && l1 < c;
-    if (r0 || r1) {
+    if (l < c) {
         const ReplayConsts k = load_consts(a.hyper, a.opt, a.bctab, a.tab_n, a.kmax);
-        const long long o = (long long)row * t0.d + cc * VEC;
-        float w[VEC], m[VEC], v[VEC], w1[1], m1[1], v1[1];
-        if (r0) { row_ld<VEC>(t0.w + o, w); row_ld<VEC>(t0.m + o, m); row_ld<VEC>(t0.v + o, v); }
-        if (r1) { w1[0] = a.t[1].w[row]; m1[0] = a.t[1].m[row]; v1[0] = a.t[1].v[row]; }
-        if (r0) {
-            replay_zero_grad_steps<VEC>(k, w, m, v, l0, c - l0);
-            row_st<VEC>(t0.w + o, w); row_st<VEC>(t0.m + o, m); row_st<VEC>(t0.v + o, v);
-        }
-        if (r1) {
-            replay_zero_grad_steps<1>(k, w1, m1, v1, l1, c - l1);
-            a.t[1].w[row] = w1[0]; a.t[1].m[row] = m1[0]; a.t[1].v[row] = v1[0];
-        }
+        replay_row_slice<VEC>(k, t, row, cc * VEC, l, c - l);
     }
     if (cc == 0) {
-        t0.last[row] = c + 1;
-        if (a.nt > 1) a.t[1].last[row] = c + 1;
+        if (a.mode == 2) { if (l < c) t.last[row] = c; }
+        else t.last[row] = c + 1;
     }
+}
+
+// Workgroup bx of the seg_catchup_blocks() that serve field f: the first nb0 replay rows of t[0] (VEC floats a lane),
+// the others rows of the 1-dim t[1] (a lane per row) -- the two tables' replay loops run in different waves.
+template <int VEC, int NT>
+__device__ __forceinline__ void catchup_seg_block(const SegCatchArgs& a, int f, int bx) {
+    if (bx < a.nb0) catchup_seg_table<VEC, NT>(a, a.t[0], f, bx);
+    else if (a.t[1].d % 4 == 0) catchup_seg_table<4, NT>(a, a.t[1], f, bx - a.nb0);
+    else catchup_seg_table<1, NT>(a, a.t[1], f, bx - a.nb0);
 }
 
 inline int fill_seg_catchup(SegCatchArgs& a, const int* seg_row, const int* counts, int F, int cap, int d, float* table,

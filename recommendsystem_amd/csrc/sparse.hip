@@ -1382,7 +1382,7 @@ int rs_sparse_dense_update_ahead(const int* plan, int F, int cap, int d, int opt
     // the replay kernel's lanes per row follow the first table it is given, as the update's do
     const int vec_c = sc.t[0].d % 4 == 0 ? 4 : 1;
     RS_CHECK_ARG(vec_c == VEC, "rs_sparse_dense_update_ahead: row width %d of the replayed table does not fit d=%d", sc.t[0].d, d);
-    const int gx = rs_cdiv(cap, 256 / a.C), sx = rs_cdiv(cap, seg_rows_per_block(sc.t[0].d, 256));
+    const int gx = rs_cdiv(cap, 256 / a.C), sx = seg_catchup_blocks(sc, 256);
     long long db = (dense_n + 255) / 256;
     const int ndb = (int)(db > 2048 ? 2048 : (db < 1 ? 1 : db));
     dim3 grid(F * sx + F * gx + ndb), block(256);

@@ -231,10 +231,19 @@ class HipShardKernels:
              self.spec.N, self.F, ptr(bk.capf_t), ptr(bk.boff_t), bk.S, bk.cap_max, self.d, ptr(table), ptr(table1),
              ptr(rows), ptr(rows1), self.W, self.W, ptr(self.layout_own.err_flag), stream())
 
+    def merge_plan(self, recv_idx):
+        """Owner: the plan of the received key lists -- every distinct row once, with the entries that name it.  It
+        depends on the keys alone, so it is made as soon as they arrive: the replay of skipped Adam steps then visits
+        every row once, and the backward pass finds its segments ready."""
+        N = self.spec.N
+        # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
+        self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
+                                  max_entries=N * self.bk.cap_max)
+
     def catch_up(self, recv_idx, rs, rs1):
         """Owner, exact Adam on touched rows: the rows the received buckets name are brought up to the current step
-        before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard)."""
-        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.bk.cap_max, self.layout_own, rs, rs1)
+        before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard); once per distinct row."""
+        self.plan_own.catchup_plan(rs, rs1, mode=2)
 
     def lookup(self, pay, bias, want_emb=True, want_sum=False, want_lr=False, want_fm=False):
         """The requester's fused lookup in the received rows: dict(emb [B,F,d], sum [B,d], lr [B], fm [B]) as K1 leaves
@@ -282,11 +291,7 @@ class HipShardKernels:
     def merge(self, recv_idx, gbuf, partials, dense=None, dense_partials=None):
         """Owner: sum the N contributions per owned row; ||g||^2 partials of the owned rows.  dense / dense_partials:
         the sum-of-squares partials of that flat buffer come out of the reduction's second launch as well."""
-        N = self.spec.N
         grads, grads1 = self._cols(gbuf)
-        # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
-        self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                  max_entries=N * self.bk.cap_max)
         self.plan_own.reduce(partials, gout=grads, g1src=grads1, Fdiv=1, ld_gout=self.W if grads is not None else 0,
                              ld_g1=self.W if grads1 is not None else 0, dense=dense, dense_partials=dense_partials)
 
@@ -331,6 +336,10 @@ class HipShardKernelsWide(HipShardKernels):
     def lookup(self, *a, **k):
         raise RSError("wide rows are expanded, not looked up")
 
+    def catch_up(self, recv_idx, rs, rs1):
+        # a row takes a whole workgroup here: per received key (the per-row form would launch a workgroup per slot)
+        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.bk.cap_max, self.layout_own, rs, rs1)
+
     def expand(self, route, pay, emb, lr1):
         call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(pay), None, ptr(emb), None,
              stream())
@@ -343,10 +352,6 @@ class HipShardKernelsWide(HipShardKernels):
              ptr(self.plan_req.rowgrad_wide), None, ptr(gbuf), None, self.W, 1, stream())
 
     def merge(self, recv_idx, gbuf, partials):
-        N = self.spec.N
-        # every received bucket is ascending (rs_shard_route keeps key order): a merge, not a sort
-        self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
-                                  max_entries=N * self.bk.cap_max)
         self.plan_own.reduce_wide(partials, gbuf.view(-1, self.d))
 
     def update(self, opt, hyper, scal, table, m, v, table1, m1, v1, rs=None, rs1=None):
@@ -394,6 +399,8 @@ class ShardedExchange:
         c.all_to_all(self.recv_idx, self.send_idx)
         if hasattr(k, "counts"):
             k.counts(self.recv_idx)
+        if hasattr(k, "merge_plan"):
+            k.merge_plan(self.recv_idx)
 
     def serve_rows(self, table, table1, rs=None, rs1=None):
         """Owner: bring the requested rows up to date (exact Adam), look them up, send them back."""
@@ -513,8 +520,9 @@ class DistributedTrainer(FusedTrainer):
         self._key_graphs = {}
         self._keys_event = None
         # a bucket that overflows serves zeros for the keys it lost: look at the flags often (they are read without a
-        # host synchronisation and reported one to two polls later, i.e. within 16 steps)
-        self.check_every = 8
+        # host synchronisation, on a stream of their own, and reported one to two polls after the device raised them:
+        # within 16 steps of the step that overflowed, the host's lead over the device included)
+        self.check_every = 6
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments

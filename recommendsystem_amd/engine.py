@@ -737,9 +737,42 @@ class FusedTrainer:
                                  t["v"].view(-1) if t["v"] is not None else None, self.opt, self.hyper, self.scal)
         if do_ahead:
             self._ahead = {"key": self._tensor_key(next_idx), "slot": 1 - slot, "B": B, "marked": self.exact and plan_mode}
-        self.last = {"dz": dz, "parts": parts}
+        self.last = {"dz": dz, "parts": parts, "plan": plan}
         del keep
         return loss
+
+    def gradients(self):
+        """name -> gradient of the last step as the reference's train_step leaves it in p.grad (model/utils/
+        BaseModel.py:141-150: backward of loss + regularization, then clip_grad_norm_): every dense parameter, and
+        every table the step looked up, dense (touched-rows mode: zeros but for the rows of the last batch, without
+        the embedding L2 term, which that mode does not take).  A checking aid: it allocates and copies."""
+        plan = self.last.get("plan")
+        if plan is None:
+            raise RSError("FusedTrainer.gradients: no step has run")
+        coef = self.scal[1]
+        out = {}
+        dense = {id(p): n for n, p in self.model.named_parameters()}
+        for pid, g in self.gviews.items():
+            if pid in dense:
+                out[dense[pid]] = g * coef
+        te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+        if self.mode == "dense":
+            full = {id(t): t["g"] for t in (te, t1) if t}
+        else:
+            full = {id(t): torch.zeros_like(t["w"]) for t in (te, t1) if t}
+            plan.scatter_dense(grad=full[id(te)] if te else None, grad1=full[id(t1)].view(-1) if t1 else None)
+        for t in (te, t1):
+            if not t:
+                continue
+            st, G = t["w"], full[id(t)]
+            row_bytes = st.element_size() * st.shape[1]
+            for n, p in self.model.named_parameters():
+                off = p.data_ptr() - st.data_ptr()
+                if p.dim() == 2 and p.shape[1] == st.shape[1] and 0 <= off < st.numel() * st.element_size() \
+                        and off % row_bytes == 0 and p.device == st.device:
+                    r = off // row_bytes
+                    out[n] = G[r:r + p.shape[0]] * coef
+        return out
 
     def _add_reg_to_loss(self, loss):
         """loss += (net/2)*||dense||^2 + (emb/2)*sum ||table||^2, evaluated on the pre-step weights."""

@@ -70,12 +70,14 @@ class FieldLayout:
 class FlagWatch:
     """Device-side error flags read without stopping the step stream: poll() looks at the copy it requested the time
     before (long since arrived in pinned host memory) and requests a new one.  A flag that is raised is therefore
-    reported between one and two polls later; check() of the owner remains the synchronous form."""
+    reported between one and two polls later (counting from the steps the device has run, which trail the steps the
+    host has issued by one or two); check() of the owner remains the synchronous form."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self._host = None
         self._event = None
+        self._stream = None
 
     def poll(self, flags):
         """flags: list of (1-element int32 device tensor, nonzero -> name); returns the names found raised in the
@@ -91,10 +93,15 @@ class FlagWatch:
             return raised
         if self._host is None or self._host.numel() != n:
             self._host = torch.zeros(n, dtype=torch.int32).pin_memory()
-        snap = torch.cat([t.view(1) for t, _ in flags])
-        self._host.copy_(snap, non_blocking=True)
-        self._event = torch.cuda.Event()
-        self._event.record()
+        # on a stream of its own and without waiting for the step stream: flags are only ever raised by the kernels, so
+        # a snapshot that misses one being raised right now shows it the next time -- and the step stream never waits
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._stream):
+            snap = torch.cat([t.view(1) for t, _ in flags])
+            self._host.copy_(snap, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
         self._names = list(flags)
         return raised
 
