@@ -743,9 +743,9 @@ class FusedTrainer:
 
     def gradients(self):
         """name -> gradient of the last step as the reference's train_step leaves it in p.grad (model/utils/
-        BaseModel.py:141-150: backward of loss + regularization, then clip_grad_norm_): every dense parameter, and
-        every table the step looked up, dense (touched-rows mode: zeros but for the rows of the last batch, without
-        the embedding L2 term, which that mode does not take).  A checking aid: it allocates and copies."""
+        BaseModel.py:141-150: backward of loss + regularization, then clip_grad_norm_): every dense parameter and every
+        table, dense (touched-rows mode: the tables the step looked up, zeros but for the rows of the last batch --
+        that mode takes no embedding L2 term).  A checking aid: it allocates and copies."""
         plan = self.last.get("plan")
         if plan is None:
             raise RSError("FusedTrainer.gradients: no step has run")
@@ -757,13 +757,13 @@ class FusedTrainer:
                 out[dense[pid]] = g * coef
         te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
         if self.mode == "dense":
-            full = {id(t): t["g"] for t in (te, t1) if t}
+            tabs = list(self.tables)             # tables the step does not look up carry their L2 term
+            full = {id(t): t["g"] for t in tabs}
         else:
-            full = {id(t): torch.zeros_like(t["w"]) for t in (te, t1) if t}
+            tabs = [t for t in (te, t1) if t]
+            full = {id(t): torch.zeros_like(t["w"]) for t in tabs}
             plan.scatter_dense(grad=full[id(te)] if te else None, grad1=full[id(t1)].view(-1) if t1 else None)
-        for t in (te, t1):
-            if not t:
-                continue
+        for t in tabs:
             st, G = t["w"], full[id(t)]
             row_bytes = st.element_size() * st.shape[1]
             for n, p in self.model.named_parameters():
