@@ -84,6 +84,10 @@ def parse():
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
+    p.add_argument("--share-launches", type=int, default=1,
+                   help="0: kernels that share a launch in the step (sort + lookup, reduction + dense norm, the two optimizer "
+                        "steps) are launched separately in the timed region too -- for counter passes, which attribute "
+                        "their readings per kernel")
     p.add_argument("--rehearse-on-one-gpu", type=int, default=0,
                    help="N>1 only: all ranks share cuda:0 and exchange through gloo with host staging (functional "
                         "rehearsal of the multi-GPU path on a one-GPU box; the numbers mean nothing)")
@@ -304,6 +308,9 @@ def main():
     else:
         eng = model.use_sparse_step(use_graph=bool(args.graph), exact_adam=bool(args.exact_adam))
 
+    if not args.share_launches and getattr(eng, "_fuse_small", False):
+        eng._fuse_small = False
+
     nb = args.distinct_batches if args.distinct_batches > 0 else args.warmup + args.steps
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))
     idx_dev = [t.to(device) for t in idxs]
@@ -432,8 +439,8 @@ def main():
             lay["launches"] += a["n"]
             lay["total_us"] += a["total_us"]
         elif a["unit"] == "byte":
-            # a launch of ~10 us: the ~4 us an empty event pair reports is a large share of it, so the figure with the
-            # raw event duration (an upper bound of the kernel's own time) is the one quoted; both are printed
+            # a launch of ~10 us: what the event pair itself adds (KernelTimer.calibrate: measured around spin kernels
+            # of known length) is a large share of the raw reading and is subtracted; the raw reading is kept beside it
             ent["avg_us_raw"] = round(a["raw_avg_us"], 2)
             ent["gbs"] = round(a["work"] / a["avg_us"] / 1e3, 1)
             ent["frac_of_peak"] = round(a["work"] / a["avg_us"] / 1e3 / HBM_PEAK_GBS, 4)
@@ -474,17 +481,19 @@ def main():
                     "event_pair_overhead_us_subtracted": round(timer.overhead_us, 2)}
     elif gather is not None:
         a, ent = gather
-        roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs_raw"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ent["frac_of_peak_raw"], "traffic": gather_traffic, "measured_in": measured_in}
+        roofline = {"bound": "hbm", "kernel": "gather_fused_kernel", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ent["frac_of_peak"], "traffic": gather_traffic, "measured_in": measured_in}
     roofline_hbm = None
     if gather is not None:
         a, ent = gather
-        roofline_hbm = {"bound": "hbm", "kernel": "gather_fused_kernel (K1)", "achieved": ent["gbs_raw"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ent["frac_of_peak_raw"], "algorithmic_bytes_per_launch": a["work"],
-                        "avg_us": ent["avg_us_raw"], "traffic": gather_traffic,
-                        "note": "duration = raw HIP-event pair (includes the pair's own ~4 us); with that overhead "
-                                f"subtracted: {ent['avg_us']} us, frac {ent['frac_of_peak']}; the rocprofv3 average of this "
-                                "kernel is in profiles/*_bench_kernel_stats.csv"}
+        roofline_hbm = {"bound": "hbm", "kernel": "gather_fused_kernel (K1)", "achieved": ent["gbs"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ent["frac_of_peak"], "algorithmic_bytes_per_launch": a["work"],
+                        "avg_us": ent["avg_us"], "traffic": gather_traffic,
+                        "note": "duration = HIP-event pair around the launch minus what the pair itself adds "
+                                f"({round(timer.overhead_us, 2)} us, measured around spin kernels of known length; raw "
+                                f"reading {ent['avg_us_raw']} us); the rocprofv3 average of gather_fused_kernel in "
+                                "profiles/*_bench_kernel_stats.csv is the same quantity (tools/collect_profiles.py "
+                                "refuses a profile where the two differ by more than 15 %)"}
 
     # K3 (sparse backward + touched-rows update) against the HBM roofline: algorithmic bytes = per entry the index and
     # the gradient row (+ the embedding row re-read where the FM term is formed on the fly), per distinct row the
@@ -532,7 +541,11 @@ def main():
                        "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
                        "distinct_batches": nb, "next_batch_announced": bool(use_next),
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
-                       "parallelism": "single GPU" if world == 1 else (
+                       "parallelism": ("single GPU" if not use_dist else
+                                       "one rank of the N>1 step (--force-dist): "
+                                       + ("replicated tables, RCCL all-gather" if args.tables == "replicated" and fused_kind
+                                          else "row-sharded tables, every all-to-all / all-reduce through RCCL on a "
+                                               "communicator of one")) if world == 1 else (
                            f"dp{world} + replicated tables (RCCL all-gather of (row, gradient) pairs)"
                            if args.tables == "replicated" and fused_kind
                            else f"dp{world} + row-sharded tables (RCCL all-to-all)")},

@@ -55,22 +55,33 @@ class KernelTimer:
         """names: entry points to time (None: every entry point that takes a stream)."""
         self.names = set(names) if names is not None else set(_lib._SIGS)
         self.records = []          # (key, work, unit, start_event, end_event)
-        self.overhead_us = 0.0     # duration an event pair reports with nothing between the two records
+        self.overhead_us = 0.0     # what an event pair adds to the duration of the kernel between its records
 
-    def calibrate(self, pairs: int = 64):
-        """Median duration of an empty event pair on the current stream (subtracted from every record)."""
-        ev = []
+    def calibrate(self, pairs: int = 48):
+        """What an event pair adds to the duration of the kernel between its two records (subtracted from every
+        record): pairs around spin kernels of two known lengths -- the duration at length zero of the line through the
+        two medians.  (A pair with nothing in between reads longer than that: the second record then waits for the
+        first one's own completion, which a kernel in between hides.)"""
         torch.cuda.synchronize()
-        torch.cuda._sleep(2000000)                 # let the host run ahead of the GPU, as in the measured pass
-        for _ in range(pairs):
-            s = torch.cuda.Event(enable_timing=True)
-            e = torch.cuda.Event(enable_timing=True)
-            s.record()
-            e.record()
-            ev.append((s, e))
-        torch.cuda.synchronize()
-        d = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
-        self.overhead_us = d[len(d) // 2]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(4000000); e1.record(); torch.cuda.synchronize()
+        cyc_per_us = 4000000 / max(e0.elapsed_time(e1) * 1e3, 1.0)
+        med = []
+        for us in (10.0, 40.0):
+            ev = []
+            torch.cuda._sleep(int(2000 * cyc_per_us))      # let the host run ahead of the GPU, as in the measured pass
+            for _ in range(pairs):
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                torch.cuda._sleep(int(us * cyc_per_us))
+                e.record()
+                ev.append((s, e))
+            torch.cuda.synchronize()
+            d = sorted(s.elapsed_time(e) * 1e3 for s, e in ev)
+            med.append(d[len(d) // 2])
+        slope = (med[1] - med[0]) / 30.0
+        self.overhead_us = max(med[0] - 10.0 * slope, 0.0)
         return self.overhead_us
 
     def __enter__(self):
@@ -103,7 +114,7 @@ class KernelTimer:
 
     def summary(self):
         """{(entry point, shape): dict(n, avg_us, total_us, raw_avg_us, work_per_launch, unit)} after a device sync;
-        raw_* are the event durations as read, the others have the empty-pair overhead subtracted."""
+        raw_* are the event durations as read, the others have the pair's own overhead (calibrate) subtracted."""
         torch.cuda.synchronize()
         agg = defaultdict(lambda: {"n": 0, "total_us": 0.0, "raw_total_us": 0.0, "work": 0.0, "unit": ""})
         for key, work, unit, s, e in self.records:

@@ -29,6 +29,22 @@ def main():
     assert os.path.isdir(src), f"{src} not found: run tools/refresh_profiles.sh {rnd} on the GPU box first"
     b = jsonl(os.path.join(src, "bench_n1.json"), 1, ("metric", "value", "roofline", "cpu_baseline"))[0]
     assert b["roofline"] and b["cpu_baseline"], "bench line without roofline / cpu_baseline"
+    # the lookup kernel's duration in the bench line and in the kernel trace of the same command are one quantity
+    k1 = b.get("roofline_hbm")
+    assert k1 and k1.get("traffic"), "bench line: roofline_hbm without traffic (counter pass lacks gather_fused_kernel?)"
+    roc = [r for r in csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv"))) if "gather_fused_kernel" in r["Name"]]
+    assert roc, "kernel stats lack gather_fused_kernel"
+    roc_us = sum(float(r["TotalDurationNs"]) for r in roc) / sum(int(r["Calls"]) for r in roc) / 1e3
+    assert abs(roc_us - k1["avg_us"]) <= 0.15 * roc_us, f"K1: bench line {k1['avg_us']} us, rocprofv3 {roc_us:.2f} us"
+    print(f"K1 lookup: bench line {k1['avg_us']} us, rocprofv3 {roc_us:.2f} us")
+    fd = jsonl(os.path.join(src, "force_dist_bench.json"), 1, ("metric", "value", "roofline", "exchange_check"))[0]
+    assert fd["exchange_check"] == "ok" and "row-sharded" in fd["config"]["parallelism"], "force_dist_bench.json is not the row-sharded step"
+    fv = jsonl(os.path.join(src, "force_dist_variants.jsonl"), 6, ("metric", "value", "config", "exchange_check"))
+    assert all(r["exchange_check"] == "ok" for r in fv)
+    assert any("rccl" in r["Name"].lower() for r in csv.DictReader(open(os.path.join(src, "force_dist_kernel_stats.csv")))), \
+        "force_dist_kernel_stats.csv holds no RCCL kernel"
+    for name in ("force_dist_step_breakdown.txt", "force_dist_two_steps.txt"):
+        assert "shard_lookup_kernel" in open(os.path.join(src, name)).read(), name
     v = jsonl(os.path.join(src, "bench_variants.jsonl"), 19, ("metric", "value", "config"))
     kinds = [r["config"]["embedding_update"].split(",")[0] for r in v]
     assert "dense" in kinds and any("lazy" in r["config"]["embedding_update"] for r in v), "variants lack the dense / lazy lines"
@@ -48,7 +64,9 @@ def main():
     mu = json.load(open(os.path.join(src, "mfma_util.json")))
     assert any(k.startswith("gemm_f32") and v["SQ_INSTS_MFMA"] > 0 for k, v in mu["kernels"].items()), "mfma_util.json lacks the GEMM"
     for name in ("bench_n1.json", "bench_variants.jsonl", "interact_roofline.jsonl", "bench_kernel_stats.csv",
-                 "interact_kernel_stats.csv", "step_breakdown.txt", "pmc_traffic.json", "mfma_util.json"):
+                 "interact_kernel_stats.csv", "step_breakdown.txt", "pmc_traffic.json", "mfma_util.json",
+                 "force_dist_bench.json", "force_dist_variants.jsonl", "force_dist_kernel_stats.csv",
+                 "force_dist_step_breakdown.txt", "force_dist_two_steps.txt"):
         shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
         print("profiles/" + f"{rnd}_{name}")
     # bench.py reads the traffic counters from the newest round's file

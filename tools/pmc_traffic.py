@@ -1,5 +1,5 @@
 """pmc_traffic.json (written beside the passes; tools/collect_profiles.py copies it into profiles/) from the two counter
-passes of tools/refresh_profiles.sh / tools/pmc_bench.sh.
+passes of tools/refresh_profiles.sh.
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE counts 128-byte read requests as
 64 bytes, so it is doubled.  Per kernel name: launches, mean read / written bytes per launch."""
@@ -42,7 +42,7 @@ def main():
     gemm = [v for k, v in kernels.items() if k.startswith("gemm_f32")]
     tot_l = sum(v["launches"] for v in gemm)
     dom = sum(v["launches"] * (v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) for v in gemm) / max(tot_l, 1)
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --graph 0 (tools/pmc_bench.sh)",
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --graph 0 --share-launches 0 (tools/refresh_profiles.sh)",
            "corrections": "values are KiB per dispatch; FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B)",
            "dominant_kernel": "gemm_f32_dma_kernel (all MLP GEMM launches of a step)",
            "dominant_kernel_hbm_bytes_per_launch": dom, "kernels": kernels}
