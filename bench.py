@@ -101,8 +101,6 @@ def build(args, device):
     vs = data.criteo_x1_vocab_sizes()
     if args.fields == 26:
         vs = vs[13:]
-    if args.model == "ffm":
-        vs = [min(v, 200000) for v in vs]       # field-aware rows are F*d floats: keep table + Adam moments in tens of GB
     rec = data.criteo_x1_recorder(embedding_dim=args.dim, batch_size=args.batch, vocab_sizes=vs)
     hidden = [int(h) for h in args.hidden.split(",") if h]
     gpu = device.index

@@ -34,6 +34,85 @@ __global__ __launch_bounds__(CT) void adam_catchup_plan_kernel(SegCatchArgs a) {
     catchup_seg_block<VEC, CT>(a, blockIdx.y, blockIdx.x);
 }
 
+// The same for rows of more than 256 floats (field-aware FFM rows, F*d up to 1024): a wave per distinct row, NS float4
+// slices per lane, the waves striding over the F lists of distinct rows laid end to end (F <= 64: lane f holds field f's
+// count).  A row whose moments are all zero does not move under Adam and is left unread; rows of the 1-dim second table
+// are served by the workgroups behind the first wide_blocks, a lane per row.
+template <int NS>
+__global__ __launch_bounds__(CT) void adam_catchup_plan_wide_kernel(SegCatchArgs a, int wide_blocks, int nb1) {
+    if ((int)blockIdx.x >= wide_blocks) {
+        const int b = blockIdx.x - wide_blocks;
+        catchup_seg_table<1, CT>(a, a.t[1], b / nb1, b % nb1);
+        return;
+    }
+    const RowTab t = a.t[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (int)*a.step;
+    const int n = lane < a.F ? a.counts[lane * 4 + 2] : 0;
+    int end = n;                                              // inclusive prefix over the fields
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(end, o);
+        if (lane >= o) end += y;
+    }
+    const int total = __shfl(end, 63);
+    const int C4 = t.d / 4;
+    const ReplayConsts k = load_consts(a.hyper, a.opt, a.bctab, a.tab_n, a.kmax);
+    for (int it = blockIdx.x * (CT / 64) + wave; it < total; it += wide_blocks * (CT / 64)) {
+        const int f = __popcll(__ballot(end <= it));          // fields that lie wholly in front of item `it`
+        const int u = it - (__shfl(end, f) - __shfl(n, f));
+        const int row = a.seg_row[(long long)f * a.cap + u];
+        const int l = t.last[row];
+        if (a.mode == 1) {
+            if (lane == 0 && l > c) t.last[row] = c;
+            continue;
+        }
+        if (l < c) {
+            constexpr int V = 4 * NS;
+            float w[V], m[V], v[V];
+            float* const pw = t.w + (long long)row * t.d;
+            float* const pm = t.m + (long long)row * t.d;
+            float* const pv = t.v + (long long)row * t.d;
+            bool nz = false;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = lane + 64 * s;
+                float4 mm = make_float4(0.f, 0.f, 0.f, 0.f), vv = mm;
+                if (i < C4) {
+                    mm = *reinterpret_cast<const float4*>(pm + 4 * i);
+                    vv = *reinterpret_cast<const float4*>(pv + 4 * i);
+                }
+                m[4 * s] = mm.x; m[4 * s + 1] = mm.y; m[4 * s + 2] = mm.z; m[4 * s + 3] = mm.w;
+                v[4 * s] = vv.x; v[4 * s + 1] = vv.y; v[4 * s + 2] = vv.z; v[4 * s + 3] = vv.w;
+                nz |= (mm.x != 0.f) | (mm.y != 0.f) | (mm.z != 0.f) | (mm.w != 0.f) | (vv.x != 0.f) | (vv.y != 0.f) |
+                      (vv.z != 0.f) | (vv.w != 0.f);
+            }
+            if (a.opt == RS_OPT_ADAMW || __ballot(nz) != 0ull) {              // uniform over the wave
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i = lane + 64 * s;
+                    float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < C4) ww = *reinterpret_cast<const float4*>(pw + 4 * i);
+                    w[4 * s] = ww.x; w[4 * s + 1] = ww.y; w[4 * s + 2] = ww.z; w[4 * s + 3] = ww.w;
+                }
+                replay_zero_grad_steps<V>(k, w, m, v, l, c - l);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i = lane + 64 * s;
+                    if (i < C4) {
+                        *reinterpret_cast<float4*>(pw + 4 * i) = make_float4(w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]);
+                        *reinterpret_cast<float4*>(pm + 4 * i) = make_float4(m[4 * s], m[4 * s + 1], m[4 * s + 2], m[4 * s + 3]);
+                        *reinterpret_cast<float4*>(pv + 4 * i) = make_float4(v[4 * s], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]);
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            if (a.mode == 2) { if (l < c) t.last[row] = c; }
+            else t.last[row] = c + 1;
+        }
+    }
+}
+
 // every row of one table up to the current step count
 template <int VEC>
 __global__ __launch_bounds__(CT) void adam_flush_kernel(RowTab t, long long rows, int opt, const long long* step,
@@ -130,6 +209,21 @@ int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, f
     const int nt = fill_seg_catchup(a, pv.seg_row, pv.counts, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step,
                                     hyper, bctab, tab_n, kmax, mode);
     RS_CHECK_ARG(nt > 0, "rs_adam_catchup_plan: no table, or a table without m / v / last, or a row width the kernels do not take (%d)", d);
+    if (a.t[0].d > 256 && a.t[0].d % 4 == 0 && F <= 64) {
+        // wide rows: a wave per row instead of a workgroup per plan slot
+        seg_catchup_blocks(a, CT);
+        const int nb1 = nt > 1 ? rs_cdiv(cap, seg_rows_per_block(a.t[1].d, CT)) : 0;
+        const long long slots = (long long)F * cap;
+        const int wide_blocks = (int)(slots / (CT / 64) + 1 < 2048 ? slots / (CT / 64) + 1 : 2048);
+        const dim3 wgrid(wide_blocks + F * nb1);
+        const int ns = rs_cdiv(a.t[0].d / 4, 64);
+        if (ns == 1) hipLaunchKernelGGL(adam_catchup_plan_wide_kernel<1>, wgrid, dim3(CT), 0, stream, a, wide_blocks, nb1);
+        else if (ns == 2) hipLaunchKernelGGL(adam_catchup_plan_wide_kernel<2>, wgrid, dim3(CT), 0, stream, a, wide_blocks, nb1);
+        else if (ns == 3) hipLaunchKernelGGL(adam_catchup_plan_wide_kernel<3>, wgrid, dim3(CT), 0, stream, a, wide_blocks, nb1);
+        else hipLaunchKernelGGL(adam_catchup_plan_wide_kernel<4>, wgrid, dim3(CT), 0, stream, a, wide_blocks, nb1);
+        RS_CHECK_LAUNCH("rs_adam_catchup_plan");
+        return RS_OK;
+    }
     const dim3 grid(seg_catchup_blocks(a, CT), F);
     if (a.t[0].d % 4 == 0) hipLaunchKernelGGL(adam_catchup_plan_kernel<4>, grid, dim3(CT), 0, stream, a);
     else hipLaunchKernelGGL(adam_catchup_plan_kernel<1>, grid, dim3(CT), 0, stream, a);

@@ -336,10 +336,6 @@ class HipShardKernelsWide(HipShardKernels):
     def lookup(self, *a, **k):
         raise RSError("wide rows are expanded, not looked up")
 
-    def catch_up(self, recv_idx, rs, rs1):
-        # a row takes a whole workgroup here: per received key (the per-row form would launch a workgroup per slot)
-        ops.adam_catchup_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.bk.cap_max, self.layout_own, rs, rs1)
-
     def expand(self, route, pay, emb, lr1):
         call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(pay), None, ptr(emb), None,
              stream())

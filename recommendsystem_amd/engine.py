@@ -69,7 +69,10 @@ class FusedTrainer:
 
     def __init__(self, model, mode: str = "sparse", max_norm: float = 10.0, use_graph: bool = False,
                  optimizer_type: Optional[str] = None, lr: Optional[float] = None, dist=None, overlap: bool = False,
-                 exact_adam: bool = True):
+                 exact_adam: bool = True, betas=(0.9, 0.999)):
+        """betas: Adam / AdamW coefficients (torch.optim's defaults, which are what the reference's optimizers run with,
+        model/utils/BaseModel.py:64-72)."""
+        self.betas = (float(betas[0]), float(betas[1]))
         kind = getattr(model, "KIND", None)
         if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
@@ -214,7 +217,7 @@ class FusedTrainer:
                                 "g": g, "used": used})
         wd = 0.01 if self.opt == "AdamW" else 0.0
         eps = 1e-10 if self.opt == "Adagrad" else 1e-8
-        self.hyper = ops.make_hyper(dev, self.lr, eps=eps, weight_decay=wd)
+        self.hyper = ops.make_hyper(dev, self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=eps, weight_decay=wd)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.scal = torch.tensor([0.0, 1.0], dtype=torch.float32, device=dev)
         self._versions = [(t["tab"], t["tab"].version) for t in self.tables]

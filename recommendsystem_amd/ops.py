@@ -819,7 +819,8 @@ class SparsePlan:
         """Exact Adam on touched rows for the DISTINCT rows of the batch this plan has sorted (main / one: the RowAdam
         states of the [R, d] and the 1-dim table).  mode 0: rows behind the step count are replayed up to it and every
         row of the plan is stamped step + 1 -- promised to the update that steps it next, which must then write no stamps
-        itself; mode 1 takes that promise back."""
+        itself; mode 1 takes that promise back; mode 2 is the plain replay (rows behind are brought up to the step count
+        and stamped with it; the update that follows stamps as usual)."""
         ref = main or one
         if ref is None:
             return
@@ -901,6 +902,12 @@ class SparsePlan:
                 raise RSError("sort_and_catchup: table and field layout disagree on the number of rows")
         if main is not None and one is not None and (main.step is not one.step or main.opt != one.opt):
             raise RSError("sort_and_catchup: the two tables belong to different optimizers")
+        if main is not None and main.d > 256 and not split_passes:
+            # rows of hundreds of floats: the sort first, then the replay with a wave per DISTINCT row (the entry-wise
+            # form elects a row's owner among the entries of a workgroup and replays the elected rows a few at a time)
+            self.sort_columnar(idx)
+            self.catchup_plan(main, one, mode=2)
+            return
         g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
         off, cnt, base = self.columnar_lists(B)
         call("rs_sort_catchup", ptr(idx), ptr(off), ptr(cnt), ptr(base), self.cap, self.CHUNK, ptr(self.layout.vocab_t),
@@ -1025,17 +1032,26 @@ class RowAdam:
 
     BC_STEPS = 1 << 16
 
-    def __init__(self, w, m, v, opt: str, hyper, step, beta1: float = 0.9, bctab=None):
+    def __init__(self, w, m, v, opt: str, hyper, step, bctab=None):
         if opt not in ("Adam", "AdamW"):
             raise RSError(f"RowAdam: {opt} has no skipped steps to replay")
         import math
+        _, beta1, beta2 = (float(x) for x in hyper[:3].tolist())     # (construction time: one host read)
         self.w, self.m, self.v = w, m, v
         self.opt, self.hyper, self.step = opt, hyper, step
         self.rows = w.shape[0]
         self.d = w.shape[1] if w.dim() == 2 else 1
         self.last = torch.zeros(self.rows, dtype=torch.int32, device=w.device)
-        # drift terms decay like beta1^j: beyond this many replayed steps they are below 1e-12 of the first one
-        self.kmax = int(math.ceil(math.log(1e-12) / math.log(beta1))) if 0.0 < beta1 < 1.0 else 1
+        # the terms of a row's drift under zero gradients, m_j / (sqrt(v_j) + eps), decay like (beta1 / sqrt(beta2))^j:
+        # beyond kmax replayed steps they are below 1e-12 of the first one and the rest is applied in closed form
+        if not (0.0 <= beta1 < 1.0 and 0.0 < beta2 < 1.0):
+            raise RSError(f"RowAdam: betas ({beta1}, {beta2}) outside [0, 1)")
+        ratio = beta1 / math.sqrt(beta2)
+        if ratio >= 1.0:
+            raise RSError(f"RowAdam: beta1 = {beta1} >= sqrt(beta2) = {math.sqrt(beta2):.6f}: the drift of an untouched row "
+                          "does not die out, so its skipped steps cannot be replayed in bounded time; use exact_adam=False "
+                          "or the dense update")
+        self.kmax = max(1, int(math.ceil(math.log(1e-12) / math.log(ratio)))) if ratio > 0.0 else 1
         self.bctab = bctab if bctab is not None else adam_bc_table(hyper, self.BC_STEPS)
 
     def catch_up(self, idx: torch.Tensor, layout: FieldLayout, mark_ahead: int = 0):

@@ -283,3 +283,50 @@ def test_out_of_range_index_raises_like_nn_embedding():
     m.train_step(x, {"label": torch.from_numpy(g["step0.label"])})
     with pytest.raises(IndexError):
         eng.check()
+
+
+def _deepfm_pair_states(betas, opt, steps=14):
+    """The same model stepped by the dense sweep and by the touched-rows step with replayed skips; (dense, exact)."""
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd.base_model import random_all
+    vocab = [7, 40, 300, 2500, 20000, 3]
+    out = []
+    for mode in ("dense", "sparse"):
+        random_all(5)
+        rec = data.criteo_x1_recorder(embedding_dim=8, batch_size=64, vocab_sizes=vocab)
+        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[32, 16], normalization=None, optimizer_type=opt)
+        m.train()
+        eng = m.use_fused_step(mode=mode, betas=betas)
+        idxs, labs = data.synthetic_batches(vocab, 64, steps, "cuda", seed=9)
+        order = [0, 1, 2, 0, 3, 4, 5, 1, 6, 7, 8, 2, 9, 0]
+        for s in range(steps):
+            eng.step_tensors(idxs[order[s]], labs[order[s]])
+        eng.check()
+        eng.flush()
+        torch.cuda.synchronize()
+        out.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    return out
+
+
+@pytest.mark.parametrize("opt", ["Adam", "AdamW"])
+@pytest.mark.parametrize("betas", [(0.9, 0.999), (0.8, 0.99), (0.95, 0.95), (0.0, 0.999)])
+def test_exact_adam_other_betas_equals_dense_sweep(betas, opt):
+    """The replay's cut-off follows the betas in use (terms decay like beta1 / sqrt(beta2)): touched-rows Adam with the
+    skipped steps replayed equals the dense sweep over all rows for coefficients other than torch's defaults too."""
+    dense, exact = _deepfm_pair_states(betas, opt)
+    assert dense.keys() == exact.keys()
+    # atol: 1e-3 of one step (lr = 1e-2; a replay that went wrong is off by whole steps).  A rare row's first gradient can be as small as eps (1e-7 .. 1e-8), where
+    # Adam's step lr * m / (sqrt(v) + eps) is no longer scale-free in g, and such a gradient carries the 1e-4 relative
+    # noise of everything upstream (the two runs differ by rounding in other rows from the first replay on).
+    for k in dense:
+        torch.testing.assert_close(exact[k], dense[k], rtol=2e-5, atol=1e-5, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_exact_adam_refuses_betas_whose_drift_does_not_decay():
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd._lib import RSError
+    rec = data.criteo_x1_recorder(embedding_dim=8, batch_size=16, vocab_sizes=[5, 9])
+    m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[8], normalization=None, optimizer_type="Adam")
+    with pytest.raises(RSError, match="sqrt"):
+        m.use_fused_step(mode="sparse", betas=(0.99, 0.9))
+    m.use_fused_step(mode="sparse", betas=(0.99, 0.9), exact_adam=False)          # the lazy form has nothing to replay
