@@ -149,9 +149,12 @@ int rs_colsum_partials(const float* X, int M, int N, int ld, const float* scale,
  * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The stage-1 partial sums
  * go to a device array the library owns (4 MiB on every GPU the library runs on, held until the process ends):
  * ceil(M/64) * N must not exceed rs_colsum_noalloc_max_floats() = 2^20, larger problems are rejected with -1.  The
- * call allocates and frees nothing; its first call on a device looks up that device's address of the array.  Every
- * call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+ * call allocates and frees nothing.  The first use on a device looks up that device's address of the array -- a
+ * runtime query, not a stream operation: make it outside any stream capture, either with one ordinary call or with
+ * rs_colsum_noalloc_prepare() (device current), after which the call may be captured.  Every call on a GPU shares
+ * that GPU's array: calls that overlap on one GPU (different streams) race. */
 size_t rs_colsum_noalloc_max_floats(void);
+int rs_colsum_noalloc_prepare(void);
 int rs_colsum_f32_noalloc(const float* X, int M, int N, int ld, const float* scale, float* out, rs_stream_t stream);
 
 /* 1-wide linear layer (the MLP head, model/DeepFM/DeepFM.py:35): h[m] = act(X[m,:].w + bias[0]) and

@@ -165,6 +165,7 @@ _PLAIN = {
     "rs_colsum_workspace_bytes": (SZ, [I, I]),
     "rs_colsum_partial_rows": (I, [I]),
     "rs_colsum_noalloc_max_floats": (SZ, []),
+    "rs_colsum_noalloc_prepare": (I, []),
     "rs_sort_plan_ints": (SZ, [I, I]),
     "rs_pnn_outer_mlp_workspace_floats": (SZ, [I, I, I, I, I, I, L]),
     "rs_pnn_outer_mlp_blocks": (I, [I, I, I, L]),

@@ -141,6 +141,19 @@ class BaseModel(nn.Module):
 
     def model_to_device(self):
         self.to(device=self.device)
+        self._number_dropouts()
+
+    def _number_dropouts(self):
+        """The mask stream of a dropout layer is keyed by (seed, salt, step): salts follow the layer's position in THIS
+        model, so that two models built alike draw the same masks from the same seed however many other models the
+        process built before (every model's constructor ends in model_to_device, as the reference's do,
+        model/DeepFM/DeepFM.py:40-41)."""
+        from .layers import Dropout
+        k = 0
+        for mod in self.modules():
+            if isinstance(mod, Dropout):
+                k += 1
+                mod.salt = k
 
     # ---- fused engine ------------------------------------------------------------------------
     def use_fused_step(self, **kw):

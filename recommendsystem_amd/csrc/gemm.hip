@@ -1286,7 +1286,11 @@ int rs_colsum_f32(const float* X, int M, int N, int ld, const float* scale, floa
     if (N == 0) return RS_OK;
     RS_CHECK_ARG(out, "rs_colsum_f32: null output");
     if (M == 0) {
-        if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream) != hipSuccess) return RS_ERR_LAUNCH;
+        const hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream);
+        if (e != hipSuccess) {
+            rs_set_error("rs_colsum_f32_noalloc: hipMemsetAsync of the %d outputs failed: %s", N, hipGetErrorString(e));
+            return RS_ERR_LAUNCH;
+        }
         return RS_OK;
     }
     RS_CHECK_ARG(X, "rs_colsum_f32: null input");
@@ -1343,6 +1347,10 @@ static float* noalloc_scratch() {
 }
 
 size_t rs_colsum_noalloc_max_floats(void) { return NOALLOC_SCRATCH_FLOATS; }
+
+// Looks up the current device's address of the array (what the first rs_colsum_f32_noalloc on a device would do): a
+// runtime query that may load the code object on that device, so it belongs in front of a stream capture, not inside.
+int rs_colsum_noalloc_prepare(void) { return noalloc_scratch() ? RS_OK : RS_ERR_LAUNCH; }
 
 int rs_colsum_f32_noalloc(const float* X, int M, int N, int ld, const float* scale, float* out, hipStream_t stream) {
     RS_CHECK_ARG(M >= 0 && N >= 0 && ld >= N, "rs_colsum_f32_noalloc: bad sizes");

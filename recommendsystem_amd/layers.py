@@ -219,7 +219,9 @@ class Dropout(nn.Dropout):
     def __init__(self, p=0.5):
         super().__init__(p)
         Dropout._salts += 1
-        self.salt = Dropout._salts          # tells the masks of different layers apart
+        # tells the masks of different layers apart; BaseModel.model_to_device() renumbers the layers of a model by
+        # their position in it, the construction counter only serves layers used outside a model
+        self.salt = Dropout._salts
 
     def forward(self, x):
         if not self.training or self.p == 0:

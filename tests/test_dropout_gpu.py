@@ -214,3 +214,30 @@ def test_stack_with_dropout_in_the_gemm_epilogues(act):
     for b, (W, bias) in zip(blocks, ps):
         torch.testing.assert_close(b.fc.weight.grad.cpu(), W.grad, rtol=1e-5, atol=5e-6)
         torch.testing.assert_close(b.fc.bias.grad.cpu(), bias.grad, rtol=1e-5, atol=5e-6)
+
+
+def test_masks_do_not_depend_on_what_was_built_before():
+    """Two models built alike, with another model (and stray layers) built in between, number their dropout layers
+    alike -- by position in the model -- and so draw the same masks from the same seed: the same first training loss."""
+    from recommendsystem_amd import data, layers, models
+    from recommendsystem_amd.base_model import random_all
+    vocab = [9, 30, 200]
+
+    def make():
+        random_all(11)
+        rec = data.criteo_x1_recorder(embedding_dim=8, batch_size=32, vocab_sizes=vocab)
+        m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[16, 8], normalization=None, dropout_rate=0.5)
+        m.train()
+        return m
+
+    a = make()
+    layers.Dropout(0.3), layers.Dropout(0.1)
+    models.DNN(data.criteo_x1_recorder(embedding_dim=4, batch_size=8, vocab_sizes=vocab), 1e-2, 0,
+               hidden_dim_list=[8], normalization=None, dropout_rate=0.2)
+    b = make()
+    salts = lambda m: [mod.salt for mod in m.modules() if isinstance(mod, layers.Dropout)]
+    assert salts(a) == salts(b) == list(range(1, len(salts(a)) + 1))
+    idxs, labs = data.synthetic_batches(vocab, 32, 1, "cuda", seed=4)
+    la = a.use_fused_step(mode="sparse").step_tensors(idxs[0], labs[0]).clone()
+    lb = b.use_fused_step(mode="sparse").step_tensors(idxs[0], labs[0]).clone()
+    assert torch.equal(la, lb)

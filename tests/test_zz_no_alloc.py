@@ -22,10 +22,14 @@ def colsum_pair(M, N, ld=None, scaled=False, seed=0):
     want = torch.full((N,), float("nan"), device="cuda")
     got = torch.full((N,), float("nan"), device="cuda")
     call("rs_colsum_f32", ptr(X), M, N, ld, ptr(scale), ptr(want), ptr(ws), ws.numel() * 4, stream())
-    before = torch.cuda.memory_allocated()
-    call("rs_colsum_f32_noalloc", ptr(X), M, N, ld, ptr(scale), ptr(got), stream())
-    assert torch.cuda.memory_allocated() == before
+    assert h.rs_colsum_noalloc_prepare() == 0          # (the address look-up of a first use is not what is measured)
+    # free device memory as the driver reports it (hipMemGetInfo: sees a hipMalloc / hipFree inside the library, which
+    # torch's own counters would not), with torch's allocator quiet: nothing is allocated between the two readings
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    call("rs_colsum_f32_noalloc", ptr(X), M, N, ld, ptr(scale), ptr(got), stream())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
     return got, want, X, scale
 
 
@@ -56,3 +60,30 @@ def test_noalloc_colsum_rejects_what_does_not_fit_and_handles_empty():
     rc = h.rs_colsum_f32_noalloc(None, 0, 8, 8, None, ptr(out), stream())     # no rows: zeros
     torch.cuda.synchronize()
     assert rc == 0 and torch.count_nonzero(out).item() == 0
+
+
+def test_noalloc_colsum_under_graph_capture():
+    """After rs_colsum_noalloc_prepare() (or one ordinary call) on the device, the call is a pair of kernel launches
+    and nothing else: captured in a HIP graph -- where an allocation or a synchronising runtime call would fail the
+    capture -- and replayed twice on changed inputs, it gives rs_colsum_f32's sums bit for bit."""
+    from recommendsystem_amd import _lib
+    from recommendsystem_amd._lib import call, ptr, stream
+    h = _lib.lib()
+    M, N = 1000, 96
+    X = torch.randn(M, N, device="cuda")
+    got = torch.zeros(N, device="cuda")
+    want = torch.zeros(N, device="cuda")
+    ws = torch.empty(max(h.rs_colsum_workspace_bytes(M, N) // 4, 1), device="cuda")
+    assert h.rs_colsum_noalloc_prepare() == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            call("rs_colsum_f32_noalloc", ptr(X), M, N, N, None, ptr(got), stream())
+    for seed in (1, 2):
+        X.copy_(torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed)))
+        g.replay()
+        call("rs_colsum_f32", ptr(X), M, N, N, None, ptr(want), ptr(ws), ws.numel() * 4, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
