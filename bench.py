@@ -373,7 +373,7 @@ def main():
         print("step host issue us:", host, file=sys.stderr)
 
     # Per-launch durations: the same K steps issued eagerly with a HIP event pair around every launch, on the
-    # launch stream.  A spin kernel in front of every step keeps the GPU busy while the host enqueues the step, so
+    # launch stream.  Matrix products in front of every step keep the GPU busy while the host enqueues the step, so
     # that each event pair brackets only its kernel (no host launch latency between the two timestamps).
     timer = KernelTimer(names=None)
     measured_in = "separate eager pass of the same K steps, HIP events around every launch"
@@ -385,16 +385,29 @@ def main():
         was_fused = getattr(eng, "_fuse_small", None)
         if was_fused:
             eng._fuse_small = False
+        # The cover in front of every step is matrix work, not a one-wave spin kernel: a GPU that has idled for
+        # milliseconds runs its next launches at lower clocks than the back-to-back replays of the timed region do.
+        cover_a = torch.randn(4096, 4096, device=device)
+        cover_b = torch.empty_like(cover_a)
+
+        def cover(ms):
+            for _ in range(max(1, int(round(ms / cover.ms_each)))):
+                torch.mm(cover_a, cover_a, out=cover_b)
+        torch.mm(cover_a, cover_a, out=cover_b)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize()
-        cycles_per_ms = 1000000 / max(e0.elapsed_time(e1), 1e-3)
+        e0.record()
+        for _ in range(4):
+            torch.mm(cover_a, cover_a, out=cover_b)
+        e1.record(); torch.cuda.synchronize()
+        cover.ms_each = max(e0.elapsed_time(e1) / 4, 1e-2)
         for i in range(2):
             eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
         torch.cuda.synchronize()
         timer.calibrate()
         with timer:
             for i in range(args.steps):
-                torch.cuda._sleep(int(6.0 * cycles_per_ms))
+                cover(6.0)
                 eng.step_tensors(idx_dev[i % nb], lab_dev[i % nb])
                 torch.cuda.synchronize()
         eng.use_graph = was_graph
