@@ -84,6 +84,8 @@ def parse():
     p.add_argument("--event-pass", type=int, default=1,
                    help="after the timed region, run the same K steps eagerly with HIP events around every launch "
                         "(per-kernel durations for the roofline figures)")
+    p.add_argument("--check-every", type=int, default=0,
+                   help="steps between two looks at the device-side error flags (0: the trainer's default)")
     p.add_argument("--share-launches", type=int, default=1,
                    help="0: kernels that share a launch in the step (sort + lookup, reduction + dense norm, the two optimizer "
                         "steps) are launched separately in the timed region too -- for counter passes, which attribute "
@@ -308,6 +310,8 @@ def main():
 
     if not args.share_launches and getattr(eng, "_fuse_small", False):
         eng._fuse_small = False
+    if args.check_every > 0:
+        eng.check_every = args.check_every
 
     nb = args.distinct_batches if args.distinct_batches > 0 else args.warmup + args.steps
     idxs, labs = data.synthetic_batches(vocab, args.batch, nb, "cpu", seed=2021 + rank, uniform=bool(args.uniform))

@@ -516,9 +516,9 @@ class DistributedTrainer(FusedTrainer):
         self._key_graphs = {}
         self._keys_event = None
         # a bucket that overflows serves zeros for the keys it lost: look at the flags often (they are read without a
-        # host synchronisation, on a stream of their own, and reported one to two polls after the device raised them:
-        # within 16 steps of the step that overflowed, the host's lead over the device included)
-        self.check_every = 6
+        # host synchronisation, on a stream of their own, and reported one to three polls after the device raised them:
+        # within 15 steps of the step that overflowed)
+        self.check_every = 5
         vocab = self.layout.vocab_sizes
         self.spec = ShardSpec(vocab, self.world, self.rank)
         # this rank's shards (training state) and their optimizer moments

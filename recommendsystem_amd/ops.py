@@ -69,22 +69,31 @@ class FieldLayout:
 
 class FlagWatch:
     """Device-side error flags read without stopping the step stream: poll() looks at the copy it requested the time
-    before (long since arrived in pinned host memory) and requests a new one.  A flag that is raised is therefore
-    reported between one and two polls later (counting from the steps the device has run, which trail the steps the
-    host has issued by one or two); check() of the owner remains the synchronous form."""
+    before (usually long since arrived in pinned host memory) and requests a new one.  A flag that is raised is
+    therefore reported one to three polls after the device raised it; check() of the owner remains the synchronous
+    form."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self._host = None
         self._event = None
         self._stream = None
+        self._pending = 0
 
     def poll(self, flags):
         """flags: list of (1-element int32 device tensor, nonzero -> name); returns the names found raised in the
         PREVIOUS snapshot (empty list if there was none yet), and requests a snapshot of the current values."""
         raised = []
         if self._event is not None:
-            self._event.synchronize()             # recorded a whole poll interval ago: returns at once
+            # The host may have issued many steps more than the device has run: a snapshot that has not arrived yet is
+            # left pending (nothing new is requested) rather than waited for; the second poll in a row that finds it
+            # pending does wait, which bounds how far the report can trail the steps the host has issued.
+            if not self._event.query():
+                self._pending += 1
+                if self._pending < 2:
+                    return raised
+                self._event.synchronize()
+            self._pending = 0
             vals = self._host.tolist()
             raised = [name for (t, name), v in zip(self._names, vals) if v != 0]
         n = len(flags)

@@ -12,7 +12,10 @@ Algorithmic bytes count every input read once and every output written once:
     dcn_cross fwd   B*(D + D)*4  (+ S)          bwd  B*(D + D + D)*4
     nfm_bi    fwd   B*(D + k)*4                 bwd  B*(D + k + D)*4
     afm       fwd   B*(D + 1)*4                 bwd  B*(D + 1 + D)*4
-    ffm       fwd   B*F*(8 + F*d*4) + B*4       bwd  fwd bytes + unique rows * F*d*4 written
+    ffm       fwd   B*F*8 + U*F*d*4 + B*4       bwd  fwd bytes + U*F*d*4 written     (U = distinct rows of the batch)
+
+FFM: a sample reads F rows of F*d floats, but a row that several samples name comes from HBM once; the bytes the
+workgroups pull through the caches (B*F*F*d*4) are reported beside it as `cache_side_MB` / `cache_side_GB_per_s`.
 """
 import json
 import os
@@ -52,9 +55,12 @@ def graph_time(fn, iters=20):
     return best
 
 
-def report(name, B, us, byts, flops=None, note=""):
+def report(name, B, us, byts, flops=None, note="", cache_bytes=None):
     line = {"kernel": name, "batch": B, "avg_us": round(us, 2), "algorithmic_MB": round(byts / 1e6, 2),
             "GB_per_s": round(byts / us / 1e3, 1), "frac_of_hbm_peak": round(byts / us / 1e3 / HBM_PEAK, 3)}
+    if cache_bytes:
+        line["cache_side_MB"] = round(cache_bytes / 1e6, 2)
+        line["cache_side_GB_per_s"] = round(cache_bytes / us / 1e3, 1)
     if flops:
         line["GFLOP"] = round(flops / 1e9, 3)
         line["TFLOP_per_s"] = round(flops / us / 1e6, 2)
@@ -107,10 +113,10 @@ def run(B):
     report("afm_fwd(A=8)", B, graph_time(lambda: ops.afm_fwd(emb, W, bA, h, pw, pb)), B * (D + 1) * 4, flops=afm_flops)
     report("afm_bwd(A=8)", B, graph_time(lambda: ops.afm_bwd(emb, do, W, bA, h, pw)), B * (2 * D + 1) * 4, flops=3 * afm_flops)
 
-    # FFM on field-aware rows of F*d floats; vocabularies as in bench.py, capped so the tables stay a few GB.
+    # FFM on field-aware rows of F*d floats; vocabularies as in bench.py (2.7 M rows: 6.8 GB, 20 GB with Adam's moments).
     # Two index distributions: skewed (hot rows, most reads served by L2 / Infinity Cache) and uniform (nearly every
-    # row distinct: the HBM-bound case the algorithmic byte count describes).
-    vocabs = [100] * 13 + [min(int(10 ** (1 + 5 * i / 25)), 200000) for i in range(26)]
+    # row distinct).
+    vocabs = [100] * 13 + [int(10 ** (1 + 5 * i / 25)) for i in range(26)]
     layout = ops.FieldLayout(vocabs, dev)
     T = torch.randn(layout.total_rows, F * d, device=dev) * 1e-2
     mT, vT = torch.zeros_like(T), torch.zeros_like(T)
@@ -126,17 +132,18 @@ def run(B):
         o = ops.ffm_fwd(idx, layout, T)
         do = torch.randn_like(o)
         uniq = sum(int(torch.unique(idx[i]).numel()) for i in range(F))
-        fb = B * F * (8 + F * d * 4) + B * 4
+        fb = B * F * 8 + uniq * F * d * 4 + B * 4          # every distinct row from HBM once
+        cb = B * F * (8 + F * d * 4) + B * 4               # what the samples read through the caches
         note = f"{dist} indices, {uniq} distinct rows of {F * d} floats among {layout.total_rows}"
-        report("ffm_fwd", B, graph_time(lambda: ops.ffm_fwd(idx, layout, T), 5), fb, note=note)
+        report("ffm_fwd", B, graph_time(lambda: ops.ffm_fwd(idx, layout, T), 5), fb, note=note, cache_bytes=cb)
         report("ffm_bwd_rows (sort + touched-row gradients)", B, graph_time(lambda: plan.rows(idx, T, do, parts), 5),
-               fb + uniq * F * d * 4, note=note)
+               fb + uniq * F * d * 4, note=note, cache_bytes=cb + uniq * F * d * 4)
         report("ffm touched-rows Adam", B, graph_time(lambda: plan.update_wide("Adam", hyper, scal, T, mT, vT), 5),
                uniq * F * d * 4 * 7, note=note + "; reads g,w,m,v and writes w,m,v")
     if B <= 4096:
         sp = ops.SparsePlan(layout, cap=B, d=1, with_lr=False)
         t = graph_time(lambda: ops.ffm_bwd(sp, idx, T, do), 3)
-        report("ffm_bwd dense dT incl. zero fill (autograd path)", B, t, fb + layout.total_rows * F * d * 4)
+        report("ffm_bwd dense dT incl. zero fill (autograd path)", B, t, fb + 2 * layout.total_rows * F * d * 4)
 
 
 if __name__ == "__main__":
