@@ -174,6 +174,17 @@ int rs_bn_fwd(const float* z, int M, int N, const float* gamma, const float* bet
               rs_stream_t stream);
 int rs_bn_bwd(const float* dh, const float* h, const float* xhat, int M, int N, int act, const float* gamma,
               const float* var, float eps, float* dgamma, float* dbeta, float* dz, rs_stream_t stream);
+/* BatchNorm1d over a batch that is spread over several GPUs (no counterpart in the reference, which is single-device;
+ * the arithmetic is its BatchNorm1d on the union batch, Layers.py:27,44): the pieces of the two calls above, between
+ * which the caller combines the ranks' results.  rs_bn_stats: this rank's mean and biased variance; the normalisation
+ * is rs_bn_fwd(training = 0) with the combined statistics; rs_bn_bwd_reduce: this rank's dbeta / dgamma sums;
+ * rs_bn_bwd_apply: dz from the sums over all m_total rows of the union batch. */
+int rs_bn_stats(const float* z, int M, int N, float* mean, float* var, rs_stream_t stream);
+int rs_bn_bwd_reduce(const float* dh, const float* h, const float* xhat, int M, int N, int act, float* dgamma,
+                     float* dbeta, rs_stream_t stream);
+int rs_bn_bwd_apply(const float* dh, const float* h, const float* xhat, int M, int N, int act, const float* gamma,
+                    const float* var, float eps, const float* dgamma_all, const float* dbeta_all, int m_total, float* dz,
+                    rs_stream_t stream);
 int rs_ln_fwd(const float* z, int M, int N, const float* gamma, const float* beta, float eps, int act, float* xhat,
               float* rstd, float* h, rs_stream_t stream);
 int rs_ln_bwd(const float* dh, const float* h, const float* xhat, const float* rstd, const float* gamma, int M, int N,

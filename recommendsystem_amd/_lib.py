@@ -111,6 +111,9 @@ _SIGS = {
     "rs_act_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, L, I, c_f32p, c_f32p, c_stream],
     "rs_bn_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, I, F, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_bn_bwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, F, c_f32p, c_f32p, c_f32p, c_stream],
+    "rs_bn_stats": [c_f32p, I, I, c_f32p, c_f32p, c_stream],
+    "rs_bn_bwd_reduce": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
+    "rs_bn_bwd_apply": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, F, c_f32p, c_f32p, I, c_f32p, c_stream],
     "rs_ln_fwd": [c_f32p, I, I, c_f32p, c_f32p, F, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_ln_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, c_stream],
     "rs_add_f32": [c_f32p, c_f32p, c_f32p, L, c_stream],

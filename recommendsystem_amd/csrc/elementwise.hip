@@ -513,10 +513,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ xhat, int M, int N, int act,
                                                            const float* __restrict__ gamma, const float* __restrict__ var,
                                                            float eps, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float* __restrict__ dz) {
+                                                           const float* __restrict__ dbeta, int m_total,
+                                                           float* __restrict__ dz) {
     const long long total = (long long)M * N;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const float invM = 1.f / (float)M;
+    const float invM = 1.f / (float)m_total;       // samples the statistics were taken over (all ranks' batches)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int n = (int)(i % N);
         const float hh = h[i];
@@ -817,8 +818,42 @@ int rs_bn_bwd(const float* dh, const float* h, const float* xhat, int M, int N, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rs_cdiv(N, 32)), dim3(256), 0, stream, dh, h, xhat, M, N, act, dgamma,
                        dbeta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_blocks((long long)M * N)), dim3(256), 0, stream, dh, h, xhat, M, N,
-                       act, gamma, var, eps, dgamma, dbeta, dz);
+                       act, gamma, var, eps, dgamma, dbeta, M, dz);
     RS_CHECK_LAUNCH("rs_bn_bwd");
+    return RS_OK;
+}
+
+// The pieces of rs_bn_fwd / rs_bn_bwd for a batch that is spread over several GPUs (one process each): the caller
+// combines the per-rank results between them, so that mean, variance and the two backward sums are those of the union
+// batch -- what the reference's single-process BatchNorm1d sees (Layers.py:27,44).
+//   rs_bn_stats       mean and biased variance (centred at that mean) of this rank's M rows
+//   rs_bn_bwd_reduce  this rank's dbeta = sum dy and dgamma = sum dy * xhat (its share of the parameter gradients)
+//   rs_bn_bwd_apply   dz from sums over all m_total rows of the union batch
+// The forward's normalisation itself is rs_bn_fwd with training = 0 and the combined statistics as mean / var.
+int rs_bn_stats(const float* z, int M, int N, float* mean, float* var, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && z && mean && var, "rs_bn_stats: bad arguments");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(rs_cdiv(N, 32)), dim3(256), 0, stream, z, M, N, mean, var);
+    RS_CHECK_LAUNCH("rs_bn_stats");
+    return RS_OK;
+}
+
+int rs_bn_bwd_reduce(const float* dh, const float* h, const float* xhat, int M, int N, int act, float* dgamma,
+                     float* dbeta, hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && dh && h && xhat && dgamma && dbeta, "rs_bn_bwd_reduce: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rs_cdiv(N, 32)), dim3(256), 0, stream, dh, h, xhat, M, N, act, dgamma,
+                       dbeta);
+    RS_CHECK_LAUNCH("rs_bn_bwd_reduce");
+    return RS_OK;
+}
+
+int rs_bn_bwd_apply(const float* dh, const float* h, const float* xhat, int M, int N, int act, const float* gamma,
+                    const float* var, float eps, const float* dgamma_all, const float* dbeta_all, int m_total, float* dz,
+                    hipStream_t stream) {
+    RS_CHECK_ARG(M > 0 && N > 0 && m_total >= M && dh && h && xhat && gamma && var && dgamma_all && dbeta_all && dz,
+                 "rs_bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(flat_blocks((long long)M * N)), dim3(256), 0, stream, dh, h, xhat, M, N,
+                       act, gamma, var, eps, dgamma_all, dbeta_all, m_total, dz);
+    RS_CHECK_LAUNCH("rs_bn_bwd_apply");
     return RS_OK;
 }
 

@@ -455,15 +455,6 @@ def _capture_with_collectives(trainer, idx, labels, next_idx=None, entry=None, r
     return FusedTrainer._capture(trainer, idx, labels, next_idx, entry, run_prologue)
 
 
-def _reject_batchnorm(model, who: str):
-    """BatchNorm statistics would be those of one rank's slice of the global batch, and the running statistics of the
-    replicas would drift apart: not the single-device step on the union batch that these trainers promise."""
-    for mod in model.modules():
-        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
-            raise RSError(f"{who}: the model has BatchNorm layers, whose batch statistics are per rank here; build the "
-                          "model with normalization='ln' or None for multi-GPU training")
-
-
 # -------------------------------------------------------------------------------------------------
 # the distributed fused step
 # -------------------------------------------------------------------------------------------------
@@ -489,7 +480,6 @@ class DistributedTrainer(FusedTrainer):
                  bucket_slack: float = 1.5, overlap_comm: Optional[bool] = None, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
-        _reject_batchnorm(model, "DistributedTrainer")
         if use_graph and stage_cpu:
             raise RSError("DistributedTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)
@@ -546,6 +536,12 @@ class DistributedTrainer(FusedTrainer):
         self.comm.broadcast(self.flat_w, 0)
 
     _ahead_kind = "keys"
+
+    def _step_impl(self, idx, labels, next_idx=None):
+        # BatchNorm layers take their batch statistics over the union of the ranks' batches (two small collectives per
+        # layer and step on the main communicator), so the replicas' running statistics stay identical
+        with ops.use_bn_sync(self.comm):
+            return super()._step_impl(idx, labels, next_idx)
 
     def _ahead_supported(self, B: int) -> bool:
         return self.overlap_comm             # the key exchange of the next batch needs the second stream and communicator
@@ -815,7 +811,6 @@ class ReplicatedTablesTrainer(FusedTrainer):
     gradients (and 1-dim gradients).  Limit: world * batch entries per field <= rs_merge_max_entries()."""
 
     def __init__(self, model, use_graph: bool = False, group=None, stage_cpu: bool = False, **kw):
-        _reject_batchnorm(model, "ReplicatedTablesTrainer")
         if use_graph and stage_cpu:
             raise RSError("ReplicatedTablesTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)
@@ -829,6 +824,10 @@ class ReplicatedTablesTrainer(FusedTrainer):
         self.comm.broadcast(self.flat_w, 0)
         for t in self.tables:
             self.comm.broadcast(t["w"], 0)
+
+    def _step_impl(self, idx, labels, next_idx=None):
+        with ops.use_bn_sync(self.comm):          # BatchNorm statistics over the union of the ranks' batches
+            return super()._step_impl(idx, labels, next_idx)
 
     def _replica(self, B: int) -> "ReplicaExchange":
         if B not in self._rp:
@@ -917,7 +916,6 @@ class DistributedSparseTrainer(SparseTrainer):
     def __init__(self, model, group=None, stage_cpu: bool = False, bucket_slack: float = 1.5, **kw):
         if kw.pop("use_graph", False):
             raise RSError("DistributedSparseTrainer: the step is issued eagerly (collectives between the launches)")
-        _reject_batchnorm(model, "DistributedSparseTrainer")
         self.comm = Comm(group, stage_cpu=stage_cpu)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.bucket_slack = bucket_slack
@@ -955,7 +953,8 @@ class DistributedSparseTrainer(SparseTrainer):
         return st, ex
 
     def _step_impl(self, inputs, y) -> torch.Tensor:
-        cap, loss = self._forward_backward(inputs, y, provider=self._provider, grad_scale=1.0 / self.world)
+        with ops.use_bn_sync(self.comm):          # BatchNorm statistics over the union of the ranks' batches
+            cap, loss = self._forward_backward(inputs, y, provider=self._provider, grad_scale=1.0 / self.world)
         jobs, seen = [], set()
         for rec in cap.records:
             g = rec["out"].grad

@@ -9,6 +9,8 @@ from __future__ import annotations
 import os
 from typing import Optional
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -1146,9 +1148,55 @@ def act_bwd(dh: torch.Tensor, act: int, z=None, h=None, slope=None):
     return dz, (colsum(parts.view(-1, 1)) if parts is not None else None)
 
 
+# BatchNorm over a batch that is spread over several GPUs: the communicator of the trainer whose step is running (an
+# object with .world, .all_gather_into(out, inp) and .all_reduce(t); None: this process holds the whole batch).
+_bn_sync = None
+
+
+@contextlib.contextmanager
+def use_bn_sync(comm):
+    """Inside the block every training-mode bn_fwd / bn_bwd takes its statistics over the union of the ranks' batches
+    (equal batch sizes on all ranks), as the reference's single-process BatchNorm1d does on the whole batch."""
+    global _bn_sync
+    prev, _bn_sync = _bn_sync, comm
+    try:
+        yield
+    finally:
+        _bn_sync = prev
+
+
+def combine_batch_stats(means: torch.Tensor, variances: torch.Tensor):
+    """(mean, biased variance) of the union of W equally large batches from their [W, N] means and biased variances:
+    the mean of the means, and the mean of the variances plus the variance of the means -- every term centred, nothing
+    cancels."""
+    mean = means.mean(0)
+    return mean, variances.mean(0) + (means - mean).pow(2).mean(0)
+
+
+def _bn_fwd_all_ranks(z, gamma, beta, act, running_mean, running_var, eps, momentum, comm):
+    M, N = z.shape
+    W = comm.world
+    st = torch.empty(2 * N, dtype=torch.float32, device=z.device)
+    call("rs_bn_stats", ptr(z), M, N, ptr(st), ptr(st[N:]), stream())
+    allst = torch.empty((W, 2 * N), dtype=torch.float32, device=z.device)
+    comm.all_gather_into(allst, st)
+    mean, var = combine_batch_stats(allst[:, :N], allst[:, N:])
+    if running_mean is not None and running_var is not None:
+        Mg = M * W
+        running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+        running_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (Mg / (Mg - 1) if Mg > 1 else 1.0))
+    h = torch.empty_like(z)
+    xhat = torch.empty_like(z)
+    call("rs_bn_fwd", ptr(z), M, N, ptr(gamma), ptr(beta), float(eps), int(act), 0, float(momentum), ptr(mean), ptr(var),
+         None, None, ptr(xhat), ptr(h), stream())
+    return h, xhat, var
+
+
 def bn_fwd(z, gamma, beta, act: int, training: bool, running_mean, running_var, eps=1e-5, momentum=0.1):
     """Returns (h, xhat, var_used).  In eval mode the running statistics are used."""
     _chk(z, torch.float32, "z")
+    if training and _bn_sync is not None:
+        return _bn_fwd_all_ranks(z, gamma, beta, act, running_mean, running_var, eps, momentum, _bn_sync)
     M, N = z.shape
     h = torch.empty_like(z)
     xhat = torch.empty_like(z)
@@ -1166,6 +1214,17 @@ def bn_fwd(z, gamma, beta, act: int, training: bool, running_mean, running_var, 
 def bn_bwd(dh, h, xhat, act: int, gamma, var, eps=1e-5):
     M, N = dh.shape
     dz = torch.empty_like(dh)
+    if _bn_sync is not None:
+        # dgamma / dbeta of THIS rank's rows are its share of the parameter gradients (the trainer's all-reduce of the
+        # dense gradient sums the shares); dz needs the sums over the union batch
+        comm = _bn_sync
+        loc = torch.empty(2 * N, dtype=torch.float32, device=dh.device)
+        call("rs_bn_bwd_reduce", ptr(dh), ptr(h), ptr(xhat), M, N, int(act), ptr(loc), ptr(loc[N:]), stream())
+        tot = loc.clone()
+        comm.all_reduce(tot)
+        call("rs_bn_bwd_apply", ptr(dh), ptr(h), ptr(xhat), M, N, int(act), ptr(gamma), ptr(var), float(eps), ptr(tot),
+             ptr(tot[N:]), M * comm.world, ptr(dz), stream())
+        return dz, loc[:N], loc[N:]
     dgamma = torch.empty(N, dtype=torch.float32, device=dh.device)
     dbeta = torch.empty(N, dtype=torch.float32, device=dh.device)
     call("rs_bn_bwd", ptr(dh), ptr(h), ptr(xhat), M, N, int(act), ptr(gamma), ptr(var), float(eps), ptr(dgamma),

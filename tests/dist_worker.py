@@ -182,7 +182,10 @@ def build_gpu_model(kind, optimizer, batch):
     random_all(11)
     rec = data.criteo_x1_recorder(embedding_dim=GPU_DIM, batch_size=batch, vocab_sizes=vocab)
     kw = dict(optimizer_type=optimizer if optimizer != "Adagrad" else "SGD")
-    hid = dict(hidden_dim_list=[64, 32], normalization=None)
+    # "<kind>_bn": the reference's default towers (BatchNorm in every block, Layers.py:9)
+    norm = "bn" if kind.endswith("_bn") else None
+    kind = kind[:-3] if norm else kind
+    hid = dict(hidden_dim_list=[64, 32], normalization=norm)
     if kind == "deepfm":
         m = models.DeepFM(rec, 1e-2, 0, **hid, **kw)
     elif kind == "fm":

@@ -31,12 +31,41 @@ def single_gpu_reference(kind, optimizer, world, generic=False):
     return m, losses
 
 
+def compare_weights(got, m, kind, optimizer):
+    """Weights of the multi-rank run against the single-GPU run on the union batch: rtol 2e-4, atol 2e-6.  Towers with
+    BatchNorm under Adam-type optimizers: the batch sum of a BatchNorm input's gradient is exactly zero, so the weight
+    gradients of an input column that is (nearly) constant over the batch -- rank_batch gives field 1 a single key per
+    rank -- are rounding noise, which Adam normalises to steps of up to lr (SGD runs of the same towers are held to the
+    tight tolerance).  There, 85 % of every tensor must meet the tight tolerance and all of it half a step (lr = 1e-2)."""
+    noisy = kind.endswith("_bn") and optimizer != "SGD"
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        a, b = torch.from_numpy(got[k]), v.cpu()
+        if not noisy:
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+            continue
+        if k.endswith(".fc.bias"):
+            continue                 # the bias in front of a BatchNorm: gradient exactly zero, all of it noise
+        if k.endswith(".norm_layer.running_mean"):
+            # ... and every step's batch mean carries that bias as it was then: bounded by the noise's size only
+            assert float((a - b).abs().max()) <= 5e-3, f"{k}: greatest difference {float((a - b).abs().max())}"
+            continue
+        bad = (a - b).abs() > 2e-6 + 2e-4 * b.abs()
+        assert float(bad.float().mean()) <= 0.15, f"{k}: {int(bad.sum())} of {bad.numel()} elements off"
+        assert float((a - b).abs().max()) <= 5e-3, f"{k}: greatest difference {float((a - b).abs().max())}"
+
+
 @pytest.mark.parametrize("kind,optimizer,extra", [("deepfm", "SGD", ""), ("deepfm", "Adam", ""), ("fm", "Adagrad", ""),
                                                   ("lr", "AdamW", ""), ("dnn", "Adam", ""),
-                                                  ("deepfm", "Adam", "onestream"), ("fm", "SGD", "onestream")])
+                                                  ("deepfm", "Adam", "onestream"), ("fm", "SGD", "onestream"),
+                                                  ("deepfm_bn", "SGD", ""), ("deepfm_bn", "Adam", ""),
+                                                  ("dnn_bn", "SGD", "onestream")])
 def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
     """Default: the dense all-reduce on a second stream and communicator beside the gradient exchange; onestream:
-    everything on one stream (the dense gradient's norm partials then ride in the owner's reduction)."""
+    everything on one stream (the dense gradient's norm partials then ride in the owner's reduction).  *_bn: towers with
+    BatchNorm in every block (the reference's default): batch statistics over the union of the ranks' batches, running
+    statistics included in the comparison."""
     world = 2
     codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer] + ([extra] if extra else []), timeout=200)
     assert codes == [0] * world, "\n".join(outs)
@@ -45,14 +74,11 @@ def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path
     # mean loss over the union batch = mean of the ranks' local means (equal batch sizes)
     lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
     np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
-    for k, v in m.state_dict().items():
-        if not v.dtype.is_floating_point:
-            continue
-        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+    compare_weights(got, m, kind, optimizer)
 
 
 @pytest.mark.parametrize("kind,optimizer", [("pnn", "Adam"), ("dcn", "SGD"), ("nfm", "Adagrad"), ("afm", "AdamW"),
-                                            ("ffm", "Adam"), ("ffm", "SGD")])
+                                            ("ffm", "Adam"), ("ffm", "SGD"), ("dcn_bn", "SGD"), ("pnn_bn", "SGD")])
 def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tmp_path):
     """DistributedSparseTrainer (model forward under autograd, sharded lookups) against SparseTrainer on the union."""
     world = 2
@@ -62,14 +88,12 @@ def test_two_ranks_generic_step_match_single_gpu_union_batch(kind, optimizer, tm
     m, losses = single_gpu_reference(kind, optimizer, world, generic=True)
     lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
     np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
-    for k, v in m.state_dict().items():
-        if not v.dtype.is_floating_point:
-            continue
-        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+    compare_weights(got, m, kind, optimizer)
 
 
 @pytest.mark.parametrize("kind,optimizer,extra", [("deepfm", "Adam", "replicated"), ("fm", "SGD", "replicated"),
-                                                  ("lr", "AdamW", "replicated"), ("deepfm", "Adagrad", "replicated")])
+                                                  ("lr", "AdamW", "replicated"), ("deepfm", "Adagrad", "replicated"),
+                                                  ("deepfm_bn", "SGD", "replicated")])
 def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
     """ReplicatedTablesTrainer: every rank keeps whole tables and merges the all-gathered (row, gradient) pairs."""
     world = 2
@@ -79,10 +103,7 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
     m, losses = single_gpu_reference(kind, optimizer, world)
     lr = np.mean([np.load(tmp_path / f"loss{r}.npy") for r in range(world)], 0)
     np.testing.assert_allclose(lr, np.array(losses), rtol=2e-5)
-    for k, v in m.state_dict().items():
-        if not v.dtype.is_floating_point:
-            continue
-        torch.testing.assert_close(torch.from_numpy(got[k]), v.cpu(), rtol=2e-4, atol=2e-6, msg=lambda s, k=k: f"{k}: {s}")
+    compare_weights(got, m, kind, optimizer)
 
 
 @pytest.mark.parametrize("kind,optimizer", [("deepfm", "Adam"), ("deepfm", "SGD"), ("fm", "AdamW"), ("lr", "Adagrad"),

@@ -109,15 +109,16 @@ def test_bench_rank_failure_ends_the_launch():
     assert r.returncode != 0 and "needs an MI355X" in r.stderr
 
 
-def test_distributed_trainers_reject_batchnorm_towers():
-    """Per-rank batch statistics are not the single-device step on the union batch: refused at construction, before
-    any process group is needed."""
-    import pytest
-    from recommendsystem_amd import data, models
-    from recommendsystem_amd._lib import RSError
-    from recommendsystem_amd.dist import DistributedSparseTrainer, DistributedTrainer, ReplicatedTablesTrainer
-    rec = data.criteo_x1_recorder(embedding_dim=4, batch_size=8, vocab_sizes=[5, 7])
-    m = models.DNN(rec, 1e-3, -1, hidden_dim_list=[8], normalization="bn")
-    for cls in (DistributedTrainer, ReplicatedTablesTrainer, DistributedSparseTrainer):
-        with pytest.raises(RSError, match="BatchNorm"):
-            cls(m)
+def test_batch_statistics_of_the_union_from_per_rank_statistics():
+    """What BatchNorm on several GPUs all-gathers and combines (ops.combine_batch_stats) against the statistics of the
+    concatenated batch, with a large common offset (where E[x^2] - E[x]^2 would lose every digit)."""
+    import torch
+    from recommendsystem_amd import ops
+    g = torch.Generator().manual_seed(0)
+    parts = [torch.randn(64, 9, generator=g, dtype=torch.float64) * (0.1 + r) + 1000.0 * (r % 2) + 5e3 for r in range(4)]
+    means = torch.stack([p.mean(0) for p in parts]).float()
+    variances = torch.stack([p.var(0, unbiased=False) for p in parts]).float()
+    mean, var = ops.combine_batch_stats(means, variances)
+    union = torch.cat(parts, 0)
+    torch.testing.assert_close(mean.double(), union.mean(0), rtol=1e-6, atol=0)
+    torch.testing.assert_close(var.double(), union.var(0, unbiased=False), rtol=1e-5, atol=0)
