@@ -107,7 +107,7 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
 
 
 @pytest.mark.parametrize("kind,optimizer", [("deepfm", "Adam"), ("deepfm", "SGD"), ("fm", "AdamW"), ("lr", "Adagrad"),
-                                            ("dnn", "Adam")])
+                                            ("dnn", "Adam"), ("deepfm_bn", "SGD")])
 def test_one_rank_rccl_graph_matches_eager(kind, optimizer, tmp_path):
     """The real RCCL calls on a one-rank group: the step issued eagerly, the whole step as ONE HIP graph with the
     collectives captured inside, that graph with the dense all-reduce on the second stream and communicator, and (eagerly
