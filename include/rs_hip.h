@@ -392,6 +392,19 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
                                float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
                                const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
                                rs_stream_t stream);
+/* rs_sparse_bwd_reduce_sumsq whose row gradients go where a table of positions says: segment u of field f writes its
+ * sum to position route[f * cap + u] of `rows` (ld_row floats per position) and its 1-dim sum to the same position of
+ * `rows1` (ld_row1 floats per position; may be a column of `rows`); a negative position drops the gradient.  The
+ * requester side of the row-sharded exchange: one gradient per distinct key straight into the bucket positions of the
+ * send buffer (rs_shard_route's route), without a compact rowgrad and a packing launch in between. */
+int rs_sparse_bwd_reduce_routed(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                                float* chunk_sum, float* chunk_sum1, float* rows, float* rows1, float* norm_partials,
+                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
+                                float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                                const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                                const int* route, int ld_row, int ld_row1, rs_stream_t stream);
 /* The same reduction for rows of W floats (W % 4 == 0, W <= 1024; field-aware FFM rows on the row-sharded path):
  * rowgrad[f, s, :] = sum of gout[sorted_src[q], :] over the entries of segment s, in ascending order; chunk_part
  * [F, cap, W] is scratch; norm_partials has rs_sparse_bwd_wide_num_partials(F, cap) floats.  The plan's window L
@@ -486,6 +499,14 @@ int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, i
 int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
                          float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
                          const float* bctab, int tab_n, int kmax, int mode, rs_stream_t stream);
+/* rs_adam_catchup_plan(mode 2) that also serves the rows: every row of the plan, once up to date, is written to each
+ * position that names it (sorted_src of the entries of its segment) of `pay` (ld_pay floats per position; the d-wide row
+ * at column col, the 1-dim value at column col1) -- rs_shard_gather for the owner of a row-sharded table whose rows the
+ * replay has just had in its registers.  Rows of up to 256 floats. */
+int rs_adam_catchup_serve(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
+                          float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
+                          const float* bctab, int tab_n, int kmax, float* pay, int ld_pay, int col, int col1,
+                          rs_stream_t stream);
 int rs_sparse_dense_update_ahead(const int* plan, int F, int cap, int d, int opt, const float* rowgrad, const float* rowgrad1,
                                  float* table, float* m, float* v, float* table1, float* m1, float* v1, float* dense_w,
                                  const float* dense_g, float* dense_m, float* dense_v, long long dense_n, const float* hyper,

@@ -71,6 +71,10 @@ _SIGS = {
                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, I,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, I, I, c_stream],
+    "rs_sparse_bwd_reduce_routed": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, I,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, I, I, I, c_i32p, I, I, c_stream],
     "rs_sparse_dense_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_i32p, c_i32p, c_i64p, c_stream],
     "rs_sparse_update": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
@@ -91,6 +95,8 @@ _SIGS = {
                         c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p, c_f32p, c_f32p, I, I, I, c_stream],
     "rs_adam_catchup_plan": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p,
                              c_f32p, c_f32p, I, I, I, c_stream],
+    "rs_adam_catchup_serve": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, I, c_i64p,
+                              c_f32p, c_f32p, I, I, c_f32p, I, I, I, c_stream],
     "rs_sparse_dense_update_ahead": [c_i32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                      c_f32p, c_f32p, c_f32p, c_f32p, L, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i64p,
                                      c_f32p, I, I, c_stream],

@@ -42,7 +42,7 @@ template <int NS>
 __global__ __launch_bounds__(CT) void adam_catchup_plan_wide_kernel(SegCatchArgs a, int wide_blocks, int nb1) {
     if ((int)blockIdx.x >= wide_blocks) {
         const int b = blockIdx.x - wide_blocks;
-        catchup_seg_table<1, CT>(a, a.t[1], b / nb1, b % nb1);
+        catchup_seg_table<1, CT>(a, 1, b / nb1, b % nb1);
         return;
     }
     const RowTab t = a.t[0];
@@ -197,9 +197,10 @@ int rs_adam_catchup_lists(const int64_t* keys, const int* sub_off, const int* su
 // (stamps above *step return to *step) when that update does not come; mode 2 is rs_adam_catchup per distinct row
 // (rows below *step brought up to it and stamped *step; the update that follows stamps as usual).  No atomics: a plan
 // names a row once.
-int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
-                         float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
-                         const float* bctab, int tab_n, int kmax, int mode, hipStream_t stream) {
+static int catchup_plan_impl(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
+                             float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
+                             const float* bctab, int tab_n, int kmax, int mode, float* pay, int ld_pay, int col, int col1,
+                             hipStream_t stream) {
     RS_CHECK_ARG(plan && step && hyper, "rs_adam_catchup_plan: null pointer");
     RS_CHECK_ARG(opt == RS_OPT_ADAM || opt == RS_OPT_ADAMW, "rs_adam_catchup_plan: optimizer %d has nothing to replay", opt);
     RS_CHECK_ARG(F > 0 && cap > 0 && kmax >= 0 && tab_n >= 0 && (tab_n == 0 || bctab), "rs_adam_catchup_plan: bad sizes");
@@ -209,6 +210,16 @@ int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, f
     const int nt = fill_seg_catchup(a, pv.seg_row, pv.counts, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step,
                                     hyper, bctab, tab_n, kmax, mode);
     RS_CHECK_ARG(nt > 0, "rs_adam_catchup_plan: no table, or a table without m / v / last, or a row width the kernels do not take (%d)", d);
+    if (pay) {
+        const int c0 = table ? col : col1;           // column of t[0]: the d-wide table when there is one
+        RS_CHECK_ARG(mode == 2 && a.t[0].d <= 256, "rs_adam_catchup_serve: rows are served by the plain replay of rows up to 256 floats");
+        RS_CHECK_ARG(ld_pay >= 1 && c0 >= 0 && c0 + a.t[0].d <= ld_pay && (nt < 2 || (col1 >= 0 && col1 < ld_pay)),
+                     "rs_adam_catchup_serve: columns %d / %d do not fit positions of %d floats", col, col1, ld_pay);
+        RS_CHECK_ARG(a.t[0].d % 4 != 0 || (ld_pay % 4 == 0 && c0 % 4 == 0 && (reinterpret_cast<uintptr_t>(pay) & 15) == 0),
+                     "rs_adam_catchup_serve: rows of %d floats need 16-byte aligned positions", a.t[0].d);
+        a.pay = pay; a.ldp = ld_pay; a.pay_col[0] = c0; a.pay_col[1] = col1;
+        a.sorted_src = pv.sorted_src; a.chunk_start = pv.chunk_start; a.seg_first_chunk = pv.seg_first_chunk;
+    }
     if (a.t[0].d > 256 && a.t[0].d % 4 == 0 && F <= 64) {
         // wide rows: a wave per row instead of a workgroup per plan slot
         seg_catchup_blocks(a, CT);
@@ -229,6 +240,26 @@ int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, f
     else hipLaunchKernelGGL(adam_catchup_plan_kernel<1>, grid, dim3(CT), 0, stream, a);
     RS_CHECK_LAUNCH("rs_adam_catchup_plan");
     return RS_OK;
+}
+
+int rs_adam_catchup_plan(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
+                         float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
+                         const float* bctab, int tab_n, int kmax, int mode, hipStream_t stream) {
+    return catchup_plan_impl(plan, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step, hyper, bctab, tab_n, kmax,
+                             mode, nullptr, 0, 0, 0, stream);
+}
+
+// rs_adam_catchup_plan(mode 2) that also SERVES the rows: every row of the plan, once up to date, is written to each
+// position that names it (the plan's entries of its segment: sorted_src) of `pay`, a buffer of ld_pay floats per
+// position -- the d-wide row at column `col`, the 1-dim value at column `col1`.  What rs_shard_gather does for the owner
+// of a row-sharded table, without a second pass over the rows the replay has just touched.  Rows of up to 256 floats.
+int rs_adam_catchup_serve(const int* plan, int F, int cap, int d, float* table, float* m, float* v, int* last, float* table1,
+                          float* m1, float* v1, int* last1, int opt, const long long* step, const float* hyper,
+                          const float* bctab, int tab_n, int kmax, float* pay, int ld_pay, int col, int col1,
+                          hipStream_t stream) {
+    RS_CHECK_ARG(pay, "rs_adam_catchup_serve: null row buffer");
+    return catchup_plan_impl(plan, F, cap, d, table, m, v, last, table1, m1, v1, last1, opt, step, hyper, bctab, tab_n, kmax,
+                             2, pay, ld_pay, col, col1, stream);
 }
 
 int rs_adam_flush(float* table, float* m, float* v, int* last, long long rows, int d, int opt, const long long* step,

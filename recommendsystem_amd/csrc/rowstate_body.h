@@ -212,6 +212,12 @@ struct SegCatchArgs {
     int opt; const long long* step;
     const float* hyper; const float* bctab; int tab_n; int kmax;
     int mode;
+    // pay != null (mode 2): the row, once up to date, is also written to every position that names it -- the entries of
+    // its segment in the plan, sorted_src[f, e] for e in [chunk_start[first chunk], chunk_start[end chunk]) -- of a buffer
+    // of ldp floats per position, table t at column pay_col[t]: the owner of a row-sharded table serves the rows it has
+    // just replayed without a second pass over them
+    float* pay; int ldp; int pay_col[2];
+    const int* sorted_src; const int* chunk_start; const int* seg_first_chunk;
 };
 
 // rows a workgroup of NT threads serves: one per group of C lanes (C = lanes of a row of width d)
@@ -229,7 +235,8 @@ inline int seg_catchup_blocks(SegCatchArgs& a, int NT) {
 // One table: workgroup bx of the ceil(cap / rows per block) that serve field f.  A group of C lanes per distinct row:
 // every lane reads the row's stamp and replays its slice (VEC floats), lane 0 writes the new stamp.
 template <int VEC, int NT>
-__device__ __forceinline__ void catchup_seg_table(const SegCatchArgs& a, const RowTab& t, int f, int bx) {
+__device__ __forceinline__ void catchup_seg_table(const SegCatchArgs& a, int ti, int f, int bx) {
+    const RowTab& t = a.t[ti];
     const int C = t.d / VEC;
     const int rpb = NT / C > 0 ? NT / C : 1;
     const int nseg = a.counts[f * 4 + 2];
@@ -249,9 +256,27 @@ __device__ __forceinline__ void catchup_seg_table(const SegCatchArgs& a, const R
         if (cc == 0 && l > c) t.last[row] = c;
         return;
     }
+    const long long o = (long long)row * t.d + cc * VEC;
+    float w[VEC];
     if (l < c) {
         const ReplayConsts k = load_consts(a.hyper, a.opt, a.bctab, a.tab_n, a.kmax);
-        replay_row_slice<VEC>(k, t, row, cc * VEC, l, c - l);
+        float m[VEC], v[VEC];
+        row_ld<VEC>(t.w + o, w);
+        row_ld<VEC>(t.m + o, m);
+        row_ld<VEC>(t.v + o, v);
+        replay_zero_grad_steps<VEC>(k, w, m, v, l, c - l);
+        row_st<VEC>(t.w + o, w);
+        row_st<VEC>(t.m + o, m);
+        row_st<VEC>(t.v + o, v);
+    } else if (a.pay) {
+        row_ld<VEC>(t.w + o, w);
+    }
+    if (a.pay) {
+        const int* sfc = a.seg_first_chunk + (long long)f * (a.cap + 1);
+        const int* cst = a.chunk_start + (long long)f * (a.cap + 1);
+        const int e0 = cst[sfc[u]], e1 = cst[sfc[u + 1]];
+        float* dst = a.pay + a.pay_col[ti] + cc * VEC;
+        for (int e = e0; e < e1; ++e) row_st<VEC>(dst + (long long)a.sorted_src[(long long)f * a.cap + e] * a.ldp, w);
     }
     if (cc == 0) {
         if (a.mode == 2) { if (l < c) t.last[row] = c; }
@@ -263,9 +288,9 @@ __device__ __forceinline__ void catchup_seg_table(const SegCatchArgs& a, const R
 // the others rows of the 1-dim t[1] (a lane per row) -- the two tables' replay loops run in different waves.
 template <int VEC, int NT>
 __device__ __forceinline__ void catchup_seg_block(const SegCatchArgs& a, int f, int bx) {
-    if (bx < a.nb0) catchup_seg_table<VEC, NT>(a, a.t[0], f, bx);
-    else if (a.t[1].d % 4 == 0) catchup_seg_table<4, NT>(a, a.t[1], f, bx - a.nb0);
-    else catchup_seg_table<1, NT>(a, a.t[1], f, bx - a.nb0);
+    if (bx < a.nb0) catchup_seg_table<VEC, NT>(a, 0, f, bx);
+    else if (a.t[1].d % 4 == 0) catchup_seg_table<4, NT>(a, 1, f, bx - a.nb0);
+    else catchup_seg_table<1, NT>(a, 1, f, bx - a.nb0);
 }
 
 inline int fill_seg_catchup(SegCatchArgs& a, const int* seg_row, const int* counts, int F, int cap, int d, float* table,

@@ -303,6 +303,9 @@ struct ReduceArgs {
     float* rowgrad;              // [F, cap, d]
     float* rowgrad1;             // [F, cap] (or null)
     float* norm_partials;        // [gridDim.x * gridDim.y] of the finalize launch
+    // route != null: the gradient of segment (f, u) goes to position route[f * cap + u] of rowgrad / rowgrad1 taken as
+    // buffers of ldr / ldr1 floats per position (negative position: dropped) instead of to slot f * cap + u
+    const int* route; int ldr, ldr1;
 };
 
 template <int VEC>
@@ -490,10 +493,15 @@ __device__ __forceinline__ void segment_finalize_body(const ReduceArgs& a, int f
     }
     if (mine) {
         const int d = a.d, co = cc * VEC;
-        stv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, acc);
+        long long pos = (long long)f * a.cap + u, ldr = d, ldr1 = 1;
+        if (a.route) { pos = a.route[pos]; ldr = a.ldr; ldr1 = a.ldr1; }
+        if (pos >= 0 && a.rowgrad) stv<VEC>(a.rowgrad + pos * ldr + co, acc);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) nsq += acc[e] * acc[e];
-        if (cc == 0 && a.rowgrad1) { a.rowgrad1[(long long)f * a.cap + u] = acc1; nsq += acc1 * acc1; }
+        if (cc == 0 && a.rowgrad1) {
+            if (pos >= 0) a.rowgrad1[pos * ldr1] = acc1;
+            nsq += acc1 * acc1;
+        }
     }
     const float tot = rs_block_sum<256>(nsq, red);
     if (threadIdx.x == 0) a.norm_partials[part_index] = tot;
@@ -1205,15 +1213,15 @@ int rs_sparse_bwd_reduce(const int* plan, int F, int cap, int d, const float* go
 // (cs_* / sk_* as those entry points' arguments; the counts may be 0).  Their outputs may be part of `dense`: the
 // second launch starts after the first has ended.  dense == nullptr with n_dense_partials == 0: no dense buffer, only the
 // finishes ride along.
-int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
-                               const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
-                               float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
-                               const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
-                               const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
-                               float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
-                               const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
-                               hipStream_t stream) {
-    RS_CHECK_ARG(plan && chunk_sum && rowgrad && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
+static int reduce_sumsq_impl(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                             const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                             float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
+                             const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                             const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
+                             float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                             const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                             const int* route, int ld_row, int ld_row1, hipStream_t stream) {
+    RS_CHECK_ARG(plan && chunk_sum && (rowgrad || route) && norm_partials, "rs_sparse_bwd_reduce_sumsq: null argument");
     RS_CHECK_ARG(cs_count >= 0 && cs_count <= CF_MAX, "rs_sparse_bwd_reduce_sumsq: at most %d column-sum problems", CF_MAX);
     ColsumFinishArgs cf{};
     int cs_blocks = 0;
@@ -1242,6 +1250,12 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     a.chunk_sum = chunk_sum; a.chunk_sum1 = chunk_sum1; a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
     a.norm_partials = norm_partials;
     RS_CHECK_ARG(set_grad_strides(a, VEC, ld_gout, ld_g1, gout) == 0, "rs_sparse_bwd_reduce_sumsq: bad gradient row strides %d / %d", ld_gout, ld_g1);
+    if (route) {
+        RS_CHECK_ARG(ld_row >= d && (!rowgrad1 || ld_row1 >= 1) &&
+                     (VEC == 1 || !rowgrad || (ld_row % 4 == 0 && (reinterpret_cast<uintptr_t>(rowgrad) & 15) == 0)),
+                     "rs_sparse_bwd_reduce_routed: positions of %d / %d floats do not take rows of %d", ld_row, ld_row1, d);
+        a.route = route; a.ldr = ld_row; a.ldr1 = ld_row1;
+    }
     a.L = window_for(d);
     const int gx = rs_cdiv(cap, 256 / a.C);
     dim3 block(256), wgrid(rs_cdiv(rs_cdiv(cap, a.L), 4), F), fgrid(F * gx + n_dense_partials);
@@ -1260,6 +1274,40 @@ int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const flo
     }
     RS_CHECK_LAUNCH("rs_sparse_bwd_reduce_sumsq");
     return RS_OK;
+}
+
+int rs_sparse_bwd_reduce_sumsq(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                               const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                               float* chunk_sum, float* chunk_sum1, float* rowgrad, float* rowgrad1, float* norm_partials,
+                               const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                               const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
+                               float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                               const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                               hipStream_t stream) {
+    return reduce_sumsq_impl(plan, F, cap, d, gout, g1src, dfm, S, emb, dlr, Fdiv, chunk_sum, chunk_sum1, rowgrad, rowgrad1,
+                             norm_partials, dense, dense_n, dense_partials, n_dense_partials, cs_part, cs_rows, cs_n, cs_ld,
+                             cs_out, cs_count, sk_ws, sk_out, sk_total, sk_splitk, sk_count, ld_gout, ld_g1, nullptr, 0, 0,
+                             stream);
+}
+
+// rs_sparse_bwd_reduce_sumsq whose row gradients go where a table of positions says instead of to slot (f, u): segment u
+// of field f writes its sum to position route[f * cap + u] of `rows` (ld_row floats per position) and its 1-dim sum to
+// the same position of `rows1` (ld_row1 floats per position; may be a column of `rows`); a negative position drops the
+// gradient.  The requester side of the row-sharded exchange: one gradient per distinct key straight into the bucket
+// positions of the send buffer (what rs_shard_pack copies there from a compact rowgrad).
+int rs_sparse_bwd_reduce_routed(const int* plan, int F, int cap, int d, const float* gout, const float* g1src,
+                                const float* dfm, const float* S, const float* emb, const float* dlr, int Fdiv,
+                                float* chunk_sum, float* chunk_sum1, float* rows, float* rows1, float* norm_partials,
+                                const float* dense, long long dense_n, float* dense_partials, int n_dense_partials,
+                                const float* const* cs_part, const int* cs_rows, const int* cs_n, const int* cs_ld,
+                                float* const* cs_out, int cs_count, const float* const* sk_ws, float* const* sk_out,
+                                const long long* sk_total, const int* sk_splitk, int sk_count, int ld_gout, int ld_g1,
+                                const int* route, int ld_row, int ld_row1, hipStream_t stream) {
+    RS_CHECK_ARG(route, "rs_sparse_bwd_reduce_routed: null route");
+    return reduce_sumsq_impl(plan, F, cap, d, gout, g1src, dfm, S, emb, dlr, Fdiv, chunk_sum, chunk_sum1, rows, rows1,
+                             norm_partials, dense, dense_n, dense_partials, n_dense_partials, cs_part, cs_rows, cs_n, cs_ld,
+                             cs_out, cs_count, sk_ws, sk_out, sk_total, sk_splitk, sk_count, ld_gout, ld_g1, route, ld_row,
+                             ld_row1, stream);
 }
 
 static int fill_update(UpdateArgs& a, const int* plan, int F, int cap, int d, int* VEC) {

@@ -240,10 +240,16 @@ class HipShardKernels:
         self.plan_own.merge_lists(recv_idx.view(-1), self.sub_off, self.sub_cnt, self.pay_base, nsrc=N,
                                   max_entries=N * self.bk.cap_max)
 
-    def catch_up(self, recv_idx, rs, rs1):
+    serves_in_catch_up = True     # catch_up(..., pay=...) also writes the rows into the send buffer: no gather() launch
+
+    def catch_up(self, recv_idx, rs, rs1, pay=None):
         """Owner, exact Adam on touched rows: the rows the received buckets name are brought up to the current step
-        before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard); once per distinct row."""
-        self.plan_own.catchup_plan(rs, rs1, mode=2)
+        before they are served (rs / rs1: ops.RowAdam of the shard / the 1-dim shard); once per distinct row.  pay: the
+        row send buffer -- every row then goes from the replay's registers to the positions that asked for it."""
+        if pay is not None:
+            self.plan_own.catchup_serve(rs, rs1, pay.view(-1), self.W, 0, self.lr_col)
+        else:
+            self.plan_own.catchup_plan(rs, rs1, mode=2)
 
     def lookup(self, pay, bias, want_emb=True, want_sum=False, want_lr=False, want_fm=False):
         """The requester's fused lookup in the received rows: dict(emb [B,F,d], sum [B,d], lr [B], fm [B]) as K1 leaves
@@ -276,11 +282,18 @@ class HipShardKernels:
             call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, None, ptr(pay), None,
                  ptr(lr1), stream())
 
-    def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
-        """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1).  colsum / splitk: pending
-        column-sum and split-K finishes of the dense backward that ride in the first launch (SparsePlan.reduce)."""
+    packs_in_reduce = True       # reduce_local(route=..., gbuf=...) writes the send buffer itself: no pack() launch
+
+    def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None, route=None, gbuf=None):
+        """One gradient per distinct key of the local batch (plan_req.rowgrad / rowgrad1; with route / gbuf straight into
+        the key's bucket position of the gradient send buffer).  colsum / splitk: pending column-sum and split-K finishes
+        of the dense backward that ride in the first launch (SparsePlan.reduce)."""
+        routed = None
+        if route is not None:
+            grads, grads1 = self._cols(gbuf)
+            routed = (route, grads, grads1, self.W, self.W)
         self.plan_req.reduce(self.scratch_partials, gout=gout, dfm=dfm, S=S, emb=emb, dlr=dlr, Fdiv=self.F,
-                             colsum=colsum, splitk=splitk)
+                             colsum=colsum, splitk=splitk, routed=routed)
 
     def pack(self, route, gbuf):
         grads, grads1 = self._cols(gbuf)
@@ -339,6 +352,12 @@ class HipShardKernelsWide(HipShardKernels):
     def expand(self, route, pay, emb, lr1):
         call("rs_shard_expand", ptr(self.plan_req.plan), ptr(route), self.F, self.B, self.d, ptr(pay), None, ptr(emb), None,
              stream())
+
+    packs_in_reduce = False
+    serves_in_catch_up = False
+
+    def catch_up(self, recv_idx, rs, rs1):
+        self.plan_own.catchup_plan(rs, rs1, mode=2)
 
     def reduce_local(self, gout, dfm, S, emb, dlr):
         self.plan_req.reduce_wide(self.scratch_partials, gout)
@@ -401,9 +420,16 @@ class ShardedExchange:
     def serve_rows(self, table, table1, rs=None, rs1=None):
         """Owner: bring the requested rows up to date (exact Adam), look them up, send them back."""
         k, c = self.k, self.comm
+        served = False
         if rs is not None or rs1 is not None:
-            k.catch_up(self.recv_idx, rs, rs1)
-        k.gather(self.recv_idx, table, table1, self.pay_s)
+            served = (getattr(k, "serves_in_catch_up", False) and (rs is not None) == (table is not None)
+                      and (rs1 is not None) == (table1 is not None))
+            if served:
+                k.catch_up(self.recv_idx, rs, rs1, pay=self.pay_s)
+            else:
+                k.catch_up(self.recv_idx, rs, rs1)
+        if not served:
+            k.gather(self.recv_idx, table, table1, self.pay_s)
         c.all_to_all(self.pay_r[:self.N * self.bk.S], self.pay_s)
 
     def forward(self, idx, table, table1, emb_out, lr1_out, rs=None, rs1=None):
@@ -419,16 +445,19 @@ class ShardedExchange:
         self.send_grads(own_partials)
 
     def reduce_local(self, gout, dfm, S, emb, dlr, colsum=None, splitk=None):
+        kw = {}
         if colsum is not None or splitk is not None:
-            self.k.reduce_local(gout, dfm, S, emb, dlr, colsum=colsum, splitk=splitk)
-        else:
-            self.k.reduce_local(gout, dfm, S, emb, dlr)
+            kw.update(colsum=colsum, splitk=splitk)
+        if getattr(self.k, "packs_in_reduce", False):
+            kw.update(route=self.route, gbuf=self.g_s)
+        self.k.reduce_local(gout, dfm, S, emb, dlr, **kw)
 
     def send_grads(self, own_partials, before_merge=None, **merge_kw):
         """before_merge: called between the all-to-all and the owner's reduction (a collective of the caller's that
         the reduction's launches then build on)."""
         k, c = self.k, self.comm
-        k.pack(self.route, self.g_s)
+        if not getattr(k, "packs_in_reduce", False):
+            k.pack(self.route, self.g_s)
         c.all_to_all(self.g_r, self.g_s)
         if before_merge is not None:
             before_merge()

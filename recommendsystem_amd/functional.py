@@ -22,6 +22,14 @@ def stack_columns(x, cols) -> torch.Tensor:
     """dict of per-column (B,) tensors -> columnar [F, B] int64 index matrix (one copy)."""
     ts = [x[c] for c in cols]
     if all(t.dtype == torch.int64 for t in ts):
+        # columns that are the rows of one [F, B] matrix already (a columnar batch handed over as a dict of views):
+        # the matrix itself, no copy
+        t0 = ts[0]
+        if t0.dim() == 1 and t0.is_contiguous():
+            B, base, off0 = t0.shape[0], t0.untyped_storage().data_ptr(), t0.storage_offset()
+            if all(t.dim() == 1 and t.shape[0] == B and t.is_contiguous() and t.untyped_storage().data_ptr() == base
+                   and t.storage_offset() == off0 + i * B for i, t in enumerate(ts)):
+                return t0.as_strided((len(ts), B), (B, 1))
         return torch.stack(ts, 0)
     return torch.stack([t.long() for t in ts], 0)      # Layers.py:147 `.long()`
 

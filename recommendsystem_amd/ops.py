@@ -843,6 +843,22 @@ class SparsePlan:
              g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt],
              ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, int(mode), stream())
 
+    def catchup_serve(self, main, one, pay: torch.Tensor, ld_pay: int, col: int, col1: int):
+        """catchup_plan(mode 2) that also writes every row of the plan, once up to date, to the positions that name it
+        (the plan's entries) of `pay` (flat, ld_pay floats per position; d-wide row at column col, 1-dim value at col1)."""
+        ref = main or one
+        if ref is None:
+            raise RSError("catchup_serve: needs a RowAdam state")
+        for st in (main, one):
+            if st is not None and st.rows != self.layout.total_rows:
+                raise RSError("catchup_serve: table and field layout disagree on the number of rows")
+        _chk(pay, torch.float32, "pay")
+        g = lambda st, k: ptr(getattr(st, k)) if st is not None else None
+        call("rs_adam_catchup_serve", ptr(self.plan), self.F, self.cap, main.d if main else 1, g(main, "w"), g(main, "m"),
+             g(main, "v"), g(main, "last"), g(one, "w"), g(one, "m"), g(one, "v"), g(one, "last"), OPT_CODES[ref.opt],
+             ptr(ref.step), ptr(ref.hyper), ptr(ref.bctab), ref.bctab.shape[0], ref.kmax, ptr(pay), int(ld_pay), int(col),
+             int(col1), stream())
+
     def update_with_dense_ahead(self, opt: str, hyper, scal, dense_w, dense_g, dense_m, dense_v, next_plan: "SparsePlan",
                                 table=None, m=None, v=None, table1=None, m1=None, v1=None, rs=None, rs1=None):
         """update_with_dense (no stamps written: the rows of this plan were promised to this update by catchup_plan) and
@@ -945,10 +961,13 @@ class SparsePlan:
              ptr(self.plan), stream())
 
     def reduce(self, norm_partials: torch.Tensor, gout=None, g1src=None, dfm=None, S=None, emb=None, dlr=None,
-               Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None, ld_gout: int = 0, ld_g1: int = 0):
+               Fdiv=None, dense=None, dense_partials=None, colsum=None, splitk=None, ld_gout: int = 0, ld_g1: int = 0,
+               routed=None):
         """Row gradients + ||g||^2 partials (norm_partials: >= n_partials floats).  dense / dense_partials: also
         write the sum-of-squares partials of the flat buffer `dense` (one per element of dense_partials) from the
-        same launch.  colsum / splitk: ColsumParts.hand_over() / SplitKParts.hand_over() -- those run beside the first launch."""
+        same launch.  colsum / splitk: ColsumParts.hand_over() / SplitKParts.hand_over() -- those run beside the first launch.
+        routed = (route [F, cap] int32, rows, rows1, ld_row, ld_row1): the gradient of segment (f, u) goes to position
+        route[f, u] of rows / rows1 (flat views, ld floats per position) instead of this plan's rowgrad / rowgrad1."""
         if norm_partials.numel() < self.n_partials:
             raise RSError("sparse backward: norm_partials too small")
         # ld_gout / ld_g1: gout / g1src are columns of a wider buffer (floats between consecutive rows / values)
@@ -959,6 +978,22 @@ class SparsePlan:
                 require_cuda(t)
             else:
                 _chk(t, torch.float32, n)
+        if routed is not None:
+            route, rows, rows1, ld_row, ld_row1 = routed
+            _chk(route, torch.int32, "route", (self.F, self.cap))
+            if (rows1 is None) != (self.rowgrad1 is None):
+                raise RSError("sparse backward: routed destinations do not match the plan's tables")
+            if dense is not None:
+                _chk(dense, torch.float32, "dense")
+                _chk(dense_partials, torch.float32, "dense_partials")
+            call("rs_sparse_bwd_reduce_routed", ptr(self.plan), self.F, self.cap, self.d, ptr(gout), ptr(g1src), ptr(dfm),
+                 ptr(S), ptr(emb), ptr(dlr), int(Fdiv or self.F), ptr(self.chunk_sum), ptr(self.chunk_sum1),
+                 ptr(rows), ptr(rows1), ptr(norm_partials), ptr(dense),
+                 dense.numel() if dense is not None else 0, ptr(dense_partials if dense is not None else None),
+                 dense_partials.numel() if dense is not None else 0, *(colsum or (None, None, None, None, None, 0)),
+                 *(splitk or (None, None, None, None, 0)), int(ld_gout), int(ld_g1), ptr(route), int(ld_row), int(ld_row1),
+                 stream())
+            return
         if dense is not None or colsum is not None or splitk is not None:
             if dense is not None:
                 _chk(dense, torch.float32, "dense")
