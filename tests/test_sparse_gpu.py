@@ -486,3 +486,110 @@ def test_bce_head_matches_torch():
     torch.testing.assert_close(out["dz"].cpu(), z0.grad, rtol=1e-4, atol=1e-9)
     out2 = ops.bce_head([z0.detach().cuda(), z1.cuda()], y.float().cuda())
     assert torch.equal(out2["dz"], out["dz"])
+
+
+@pytest.mark.parametrize("B", [5, 300, 2000])
+def test_routed_reduce_equals_reduce_then_copy(B):
+    """rs_sparse_bwd_reduce_routed: the gradient of every distinct key lands at the position a route table names, in a
+    buffer of wider positions with the 1-dim gradient in a spare column -- bit for bit what the compact reduction
+    followed by a copy gives; keys whose position is negative are dropped."""
+    from recommendsystem_amd import ops
+    vocabs = [4, 60, 3000, 100000]
+    idx, g = _case(B, vocabs, seed=B)
+    dev = "cuda:0"
+    layout = ops.FieldLayout(vocabs, dev)
+    F, d, W = len(vocabs), 16, 20
+    a = ops.SparsePlan(layout, cap=B, d=d, with_lr=True)
+    b = ops.SparsePlan(layout, cap=B, d=d, with_lr=True)
+    a.sort_columnar(idx.to(dev))
+    b.sort_columnar(idx.to(dev))
+    gout = torch.randn(B * F, d, generator=g).to(dev)
+    dlr = torch.randn(B, generator=g).to(dev)
+    pa = torch.zeros(a.n_partials, device=dev)
+    pb = torch.zeros(a.n_partials, device=dev)
+    a.reduce(pa, gout=gout, dlr=dlr, Fdiv=F)
+    nseg = a.counts()[:, 2].cpu()
+    # a scattered, collision-free route; every seventh distinct key has none
+    perm = torch.randperm(F * B, generator=g).view(F, B).int()
+    perm[:, ::7] = -1
+    route = perm.to(dev)
+    buf = torch.full((F * B, W), float("nan"), device=dev)
+    flat = buf.view(-1)
+    b.reduce(pb, gout=gout, dlr=dlr, Fdiv=F, routed=(route, flat, flat[d:], W, W))
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb)                       # the norm partials count dropped keys too, as before
+    for f in range(F):
+        for u in range(int(nseg[f])):
+            pos = int(perm[f, u])
+            if pos < 0:
+                continue
+            assert torch.equal(buf[pos, :d], a.rowgrad[f, u]), (f, u)
+            assert buf[pos, d] == a.rowgrad1[f, u]
+    written = torch.zeros(F * B, dtype=torch.bool)
+    for f in range(F):
+        p = perm[f, :int(nseg[f])]
+        written[p[p >= 0].long()] = True
+    assert torch.isnan(buf[~written.to(dev)]).all()  # nothing else was touched
+
+
+@pytest.mark.parametrize("opt", ["Adam", "AdamW"])
+def test_replay_that_serves_rows_equals_replay_then_gather(opt):
+    """rs_adam_catchup_serve on the merged plan of several key lists: weights, moments and stamps as after
+    rs_adam_catchup_plan(mode 2), and every position that names a key holds the replayed row (1-dim value in its
+    column), whichever list the key came from."""
+    from recommendsystem_amd import ops
+    dev = "cuda:0"
+    vocabs = [9, 200, 5000]
+    F, d, W, nsrc, per = len(vocabs), 8, 12, 3, 64
+    layout = ops.FieldLayout(vocabs, dev)
+    g = torch.Generator().manual_seed(5)
+    R = layout.total_rows
+
+    def state():
+        gg = torch.Generator().manual_seed(6)
+        w = torch.randn(R, d, generator=gg).to(dev)
+        m = (torch.randn(R, d, generator=gg) * 0.1).to(dev)
+        v = (torch.rand(R, d, generator=gg) * 0.01).to(dev)
+        w1 = torch.randn(R, generator=gg).to(dev)
+        m1 = (torch.randn(R, generator=gg) * 0.1).to(dev)
+        v1 = (torch.rand(R, generator=gg) * 0.01).to(dev)
+        hyper = ops.make_hyper(dev, 1e-2, weight_decay=0.01 if opt == "AdamW" else 0.0)
+        step = torch.full((1,), 9, dtype=torch.int64, device=dev)
+        rs = ops.RowAdam(w, m, v, opt, hyper, step)
+        rs1 = ops.RowAdam(w1, m1, v1, opt, hyper, step, bctab=rs.bctab)
+        stamps = torch.randint(0, 10, (R,), generator=gg, dtype=torch.int32).to(dev)
+        rs.last.copy_(stamps)
+        rs1.last.copy_(stamps)
+        return rs, rs1
+
+    # nsrc ascending, duplicate-free key lists per field (keys >= 1), ragged lengths
+    keys = torch.zeros(nsrc * F, per, dtype=torch.int64)
+    cnt = torch.zeros(nsrc * F, dtype=torch.int32)
+    for s in range(nsrc):
+        for f, v in enumerate(vocabs):
+            n = int(torch.randint(0, min(per, v - 1) + 1, (1,), generator=g))
+            ks = (torch.randperm(v - 1, generator=g)[:n] + 1).sort().values
+            keys[s * F + f, :n] = ks
+            cnt[s * F + f] = n
+    sf = torch.arange(nsrc * F, dtype=torch.int32)
+    sub_off, pay_base = (sf * per).to(dev), (sf * per).to(dev)
+    plans = []
+    for _ in range(2):
+        p = ops.SparsePlan(layout, cap=nsrc * per, d=d, with_lr=True)
+        p.merge_lists(keys.to(dev).view(-1), sub_off, cnt.to(dev), pay_base, nsrc, nsrc * per)
+        plans.append(p)
+    (rs_a, rs1_a), (rs_b, rs1_b) = state(), state()
+    plans[0].catchup_plan(rs_a, rs1_a, mode=2)
+    pay = torch.full((nsrc * F * per, W), float("nan"), device=dev)
+    plans[1].catchup_serve(rs_b, rs1_b, pay.view(-1), W, 0, d)
+    torch.cuda.synchronize()
+    for x, y in ((rs_a, rs_b), (rs1_a, rs1_b)):
+        for k in ("w", "m", "v", "last"):
+            assert torch.equal(getattr(x, k), getattr(y, k)), k
+    offs = layout.row_offsets
+    for l in range(nsrc * F):
+        f = l % F
+        for j in range(int(cnt[l])):
+            row = offs[f] + int(keys[l, j])
+            assert torch.equal(pay[l * per + j, :d], rs_a.w[row]), (l, j)
+            assert pay[l * per + j, d] == rs1_a.w[row]
