@@ -322,8 +322,10 @@ class SparseTrainer:
         with ops.use_workspace(self.ws):
             return self._step_impl(inputs, self.model.labels_to_device(labels))
 
-    def _forward_backward(self, inputs, y, provider=None, grad_scale: float = 1.0):
-        """The model's forward and autograd backward with captured table lookups; dense gradients land in flat_g."""
+    def _forward_backward(self, inputs, y, provider=None, grad_scale: float = 1.0, defer_finishes: bool = False):
+        """The model's forward and autograd backward with captured table lookups; dense gradients land in flat_g.
+        defer_finishes: the split-K and column-sum finishing launches of the pass are left to the caller
+        (self._pending_finishes = (SplitKParts or None, ColsumParts or None)), who lets them ride in another launch."""
         m = self.model
         self._sorted.clear()
         self.flat_g_ext.zero_()
@@ -349,15 +351,28 @@ class SparseTrainer:
             if m.net_regular:
                 loss = loss + m.regularization_loss()
             (loss if grad_scale == 1.0 else loss * grad_scale).backward()
-            if splitk is not None:
-                splitk.finish()
-            if colsum is not None:
-                colsum.finish()          # every bias gradient (and other column sum) of the pass, one launch per eight
+            self._pending_finishes = (None, None)
+            if defer_finishes:
+                self._pending_finishes = (splitk, colsum)
+            else:
+                if splitk is not None:
+                    splitk.finish()
+                if colsum is not None:
+                    colsum.finish()      # every bias gradient (and other column sum) of the pass, one launch per eight
         return cap, loss
 
+    def _finish_pending(self):
+        splitk, colsum = self._pending_finishes
+        self._pending_finishes = (None, None)
+        if splitk is not None:
+            splitk.finish()
+        if colsum is not None:
+            colsum.finish()
+
     def _step_impl(self, inputs, y) -> torch.Tensor:
-        cap, loss = self._forward_backward(inputs, y)
+        cap, loss = self._forward_backward(inputs, y, defer_finishes=True)
         if self.exact and any(r["out"].grad is None for r in cap.records):
+            self._finish_pending()
             raise RSError("SparseTrainer: a table was looked up but its rows do not reach the loss; with exact Adam "
                           "every looked-up row must be stepped (drop the lookup or pass exact_adam=False)")
         jobs = []
@@ -375,6 +390,15 @@ class SparseTrainer:
         # one looked-up table set (every model but FFM): the dense gradient's norm partials come out of the embedding
         # reduction's second launch and the flat dense step shares the touched-rows update's launch, as in the fused engine
         single = len(jobs) == 1 and "ffm" not in jobs[0][0]
+        # ... and the finishing additions of the dense backward (weight-gradient slabs, bias-gradient partial sums) ride
+        # in the reduction's first launch; otherwise they get launches of their own now
+        carry = (None, None)
+        if single:
+            splitk, colsum = self._pending_finishes
+            self._pending_finishes = (None, None)
+            carry = (colsum.hand_over() if colsum is not None else None, splitk.hand_over() if splitk is not None else None)
+        else:
+            self._finish_pending()
         for group, plan, n in jobs:
             idx = next(iter(group.values()))["idx"]
             B = idx.shape[1]
@@ -394,7 +418,8 @@ class SparseTrainer:
                 plan.reduce(P[off:off + n], gout=ge.view(B * plan.F, plan.d) if ge is not None else None,
                             dlr=gl.view(B) if gl is not None else None,
                             dense=self.flat_g if single else None,
-                            dense_partials=P[off + n:off + n + N_DENSE_PARTIALS] if single else None)
+                            dense_partials=P[off + n:off + n + N_DENSE_PARTIALS] if single else None,
+                            colsum=carry[0], splitk=carry[1])
             if self.exact:
                 main = group.get("emb") or group.get("ffm")
                 for r in group.values():
