@@ -389,7 +389,8 @@ class SparseTrainer:
         off = 0
         # one looked-up table set (every model but FFM): the dense gradient's norm partials come out of the embedding
         # reduction's second launch and the flat dense step shares the touched-rows update's launch, as in the fused engine
-        single = len(jobs) == 1 and "ffm" not in jobs[0][0]
+        # (an FFM model's 1-dim LR lookup shares the batch with the field-aware one: its reduction and update carry them)
+        single = len(jobs) == 1 and ("ffm" not in jobs[0][0] or "lr" in jobs[0][0])
         # ... and the finishing additions of the dense backward (weight-gradient slabs, bias-gradient partial sums) ride
         # in the reduction's first launch; otherwise they get launches of their own now
         carry = (None, None)
@@ -408,7 +409,10 @@ class SparseTrainer:
                 plan.rows(idx, group["ffm"]["holder"].stacked, grad("ffm").view(B), P[off:off + nw],
                           sorted_already=self._sorted.get(id(plan)) is idx)
                 if "lr" in group:
-                    plan.reduce(P[off + nw:off + n], dlr=grad("lr").view(B))
+                    plan.reduce(P[off + nw:off + n], dlr=grad("lr").view(B),
+                                dense=self.flat_g if single else None,
+                                dense_partials=P[off + n:off + n + N_DENSE_PARTIALS] if single else None,
+                                colsum=carry[0], splitk=carry[1])
                 else:
                     P[off + nw:off + n].zero_()
             else:
