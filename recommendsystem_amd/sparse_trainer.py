@@ -79,6 +79,7 @@ class SparseTrainer:
         self._state: Dict[int, dict] = {}       # per table holder: optimizer moments
         self._plans: Dict[tuple, object] = {}
         self._partials = None
+        self._seeds = {}             # gradient scale -> the tensor handed to backward() as the loss's incoming gradient
         self.last = {}
         # scratch of this trainer's launches (split-K slabs, column-sum partials): private, so that a captured step
         # never shares a buffer with another model or with module-path calls on the same device
@@ -350,7 +351,12 @@ class SparseTrainer:
                 loss = m.criterion(out.squeeze(1), y.float())
             if m.net_regular:
                 loss = loss + m.regularization_loss()
-            (loss if grad_scale == 1.0 else loss * grad_scale).backward()
+            # the gradient arriving at the loss comes from a tensor kept for the purpose: backward() would otherwise
+            # fill a fresh one (and a scaled loss multiply it) in launches of their own
+            seed = self._seeds.get(float(grad_scale))
+            if seed is None or seed.shape != loss.shape:
+                seed = self._seeds[float(grad_scale)] = torch.full_like(loss, float(grad_scale))
+            loss.backward(seed)
             self._pending_finishes = (None, None)
             if defer_finishes:
                 self._pending_finishes = (splitk, colsum)
