@@ -122,3 +122,36 @@ def test_deepfm_benchmark_tower_dense_adam(graph):
     # Adam turns a gradient at rounding level into a step of up to lr: the floor is a fraction of 3 * lr
     run_steps("deepfm", m, o, rec, "Adam", 4096, 3, 1e-3, lambda idx, y: eng.step_tensors(idx.cuda(), y.cuda()),
               rtol=1e-4, atol_adam=2e-5)
+
+
+@pytest.mark.parametrize("opt", ["Adam", "AdamW"])
+def test_benchmark_configuration_touched_rows_equals_dense_sweep(opt):
+    """The benchmark's exact configuration -- 39 fields with the full vocabularies (2.71 M rows), embedding_dim 16, batch
+    4096, tower 624-1024-512-256-1 -- for eight steps on non-repeating Zipf batches from one HIP graph per batch: the
+    touched-rows step with replayed skips against the dense sweep over every row of every table (the reference's
+    optimizer semantics, BaseModel.py:64-72,149), which needs no CPU oracle at this size.  Losses to 1e-5; weights to 2e-5
+    with a floor of 1e-3 of one step (a rare row's first gradient can be as small as Adam's eps, where the step follows
+    the gradient's rounding noise)."""
+    from recommendsystem_amd import data, models
+    from recommendsystem_amd.base_model import random_all
+    vocab = data.criteo_x1_vocab_sizes()
+    steps, lr = 8, 1e-3
+    idxs, labs = data.synthetic_batches(vocab, 4096, steps, "cuda", seed=77)
+    out = []
+    for mode in ("dense", "sparse"):
+        random_all(3)
+        rec = data.criteo_x1_recorder(embedding_dim=16, batch_size=4096, vocab_sizes=vocab)
+        m = models.DeepFM(rec, lr, 0, hidden_dim_list=[1024, 512, 256], normalization=None, optimizer_type=opt)
+        m.train()
+        eng = m.use_fused_step(mode=mode, use_graph=(mode == "sparse"))
+        losses = [eng.step_tensors(idxs[s], labs[s], resident=True).clone() for s in range(steps)]
+        eng.check()
+        eng.flush()
+        torch.cuda.synchronize()
+        out.append((torch.cat(losses).cpu(), {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        del m, eng
+    (ld, sd), (ls, ss) = out
+    torch.testing.assert_close(ls, ld, rtol=1e-5, atol=1e-7)
+    for k in sd:
+        if sd[k].dtype.is_floating_point:
+            torch.testing.assert_close(ss[k], sd[k], rtol=2e-5, atol=1e-6, msg=lambda s_, k=k: f"{k}: {s_}")
