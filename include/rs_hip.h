@@ -297,6 +297,10 @@ int rs_dcn_cross_fwd(const float* x0, const float* w, const float* bias, int B, 
                      rs_stream_t stream);
 int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
                      int L, float* dx0, float* partials, int rows, rs_stream_t stream);
+/* rs_dcn_cross_bwd with dx0 = (the cross network's gradient of x0) + dx_add [B, D] (the deep tower's gradient of the
+ * same flattened embeddings, DCN.py:48-52); dx_add must not overlap dx0. */
+int rs_dcn_cross_bwd_add(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
+                         int L, const float* dx_add, float* dx0, float* partials, int rows, rs_stream_t stream);
 
 /* NFM bi-interaction as the reference writes it: 0.5*((E V)^2 - E^2 V^2), E[B,D], V[D,K], K <= 16
  * (model/NFM/NFM.py:42-44).  s_out[B,K] = E V is saved for the backward; partials: [rows, D*K] = dV. */

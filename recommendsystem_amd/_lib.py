@@ -150,6 +150,7 @@ _SIGS = {
                              L, c_stream],
     "rs_dcn_cross_fwd": [c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_dcn_cross_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
+    "rs_dcn_cross_bwd_add": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_f32p, I, c_stream],
     "rs_nfm_bi_fwd": [c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, c_stream],
     "rs_nfm_bi_bwd": [c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_f32p, I, c_stream],
     "rs_afm_fwd": [c_f32p, I, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream],

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void dcn_cross_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ S,
                                                             const float* __restrict__ dout, const float* __restrict__ w,
                                                             const float* __restrict__ bias, int B, int D, int L,
-                                                            float* __restrict__ dx0, float* __restrict__ partials) {
+                                                            float* __restrict__ dx0, float* __restrict__ partials,
+                                                            const float* __restrict__ dxadd) {
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int region = (2 * L + 2) * D;
@@ -501,7 +502,8 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_kernel(const float* __restr
                 part = fmaf(gn, x0n, part);
             }
         }
-        for (int n = lane; n < D; n += 64) dx0[(long long)b * D + n] = d0[n] + dx[n];
+        for (int n = lane; n < D; n += 64)
+            dx0[(long long)b * D + n] = d0[n] + dx[n] + (dxadd ? dxadd[(long long)b * D + n] : 0.f);
     }
     __syncthreads();
     float* prow = partials + (long long)blockIdx.x * 2 * L * D;
@@ -562,7 +564,8 @@ template <int T, int L>
 __global__ __launch_bounds__(256) void dcn_cross_bwd_reg_kernel(const float* __restrict__ x0, const float* __restrict__ S,
                                                                 const float* __restrict__ dout, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, int B, int D,
-                                                                float* __restrict__ dx0, float* __restrict__ partials) {
+                                                                float* __restrict__ dx0, float* __restrict__ partials,
+                                                                const float* __restrict__ dxadd) {
     extern __shared__ float sm[];        // first w | bias, at the end the four waves' accumulators [4][2*L*D]
     float* sw = sm;
     float* sbias = sm + L * D;
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(256) void dcn_cross_bwd_reg_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             const int n = lane + 64 * i;
-            if (n < D) dx0[(long long)b * D + n] = d0[i] + dx[i];
+            if (n < D) dx0[(long long)b * D + n] = d0[i] + dx[i] + (dxadd ? dxadd[(long long)b * D + n] : 0.f);
         }
     }
     __syncthreads();                     // every wave is done with w | bias
@@ -2260,8 +2263,8 @@ int rs_dcn_cross_fwd(const float* x0, const float* w, const float* bias, int B, 
 
 // dx0 [B,D]; partials [rows, 2*L*D] with rows = rs_interact_partial_rows(B): per-row [dW | dB] partial sums,
 // to be summed over rows by the caller.
-int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
-                     int L, float* dx0, float* partials, int rows, hipStream_t stream) {
+static int dcn_cross_bwd_impl(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B,
+                              int D, int L, float* dx0, float* partials, int rows, const float* dxadd, hipStream_t stream) {
     RS_CHECK_ARG(B > 0 && D > 0 && L > 0, "rs_dcn_cross_bwd: bad sizes");
     RS_CHECK_ARG(x0 && S && dout && w && bias && dx0 && partials, "rs_dcn_cross_bwd: null argument");
     RS_CHECK_ARG(rows == rs_interact_partial_rows(B), "rs_dcn_cross_bwd: partials must have %d rows",
@@ -2273,7 +2276,7 @@ int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const f
     do {                                                                                                               \
         RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(dcn_cross_bwd_reg_kernel<TT, LL>)), "rs_dcn_cross_bwd: cannot raise the LDS limit"); \
         hipLaunchKernelGGL((dcn_cross_bwd_reg_kernel<TT, LL>), dim3(rows), dim3(256), rlds, stream, x0, S, dout, w, bias, B, D, \
-                           dx0, partials);                                                                             \
+                           dx0, partials, dxadd);                                                                      \
     } while (0)
         RS_DCN_DISPATCH(RS_DCN_B, T, L)
 #undef RS_DCN_B
@@ -2285,9 +2288,23 @@ int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const f
     const int nw = waves_for(per_wave);
     RS_CHECK_ARG(raise_lds(reinterpret_cast<const void*>(dcn_cross_bwd_kernel)), "rs_dcn_cross_bwd: cannot raise the LDS limit");
     hipLaunchKernelGGL(dcn_cross_bwd_kernel, dim3(rows), dim3(64 * nw), nw * per_wave, stream, x0, S, dout, w, bias, B, D, L,
-                       dx0, partials);
+                       dx0, partials, dxadd);
     RS_CHECK_LAUNCH("rs_dcn_cross_bwd");
     return RS_OK;
+}
+
+int rs_dcn_cross_bwd(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
+                     int L, float* dx0, float* partials, int rows, hipStream_t stream) {
+    return dcn_cross_bwd_impl(x0, S, dout, w, bias, B, D, L, dx0, partials, rows, nullptr, stream);
+}
+
+// rs_dcn_cross_bwd with dx0 = (the cross network's gradient of x0) + dx_add [B, D]: x0 also feeds the deep tower
+// (model/DCN/DCN.py:48-52), whose gradient of it arrives first -- the sum needs no launch of its own.  dx_add must not
+// overlap dx0.
+int rs_dcn_cross_bwd_add(const float* x0, const float* S, const float* dout, const float* w, const float* bias, int B, int D,
+                         int L, const float* dx_add, float* dx0, float* partials, int rows, hipStream_t stream) {
+    RS_CHECK_ARG(dx_add && dx_add != dx0, "rs_dcn_cross_bwd_add: null or aliased dx_add");
+    return dcn_cross_bwd_impl(x0, S, dout, w, bias, B, D, L, dx0, partials, rows, dx_add, stream);
 }
 
 // NFM bi-interaction, reference form: E [B,D], V [D,K] -> out [B,K]; s_out [B,K] = E V is saved for the

@@ -74,7 +74,7 @@ class FusedTrainer:
         model/utils/BaseModel.py:64-72)."""
         self.betas = (float(betas[0]), float(betas[1]))
         kind = getattr(model, "KIND", None)
-        if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep"):
+        if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
         if mode not in ("sparse", "dense"):
             raise ValueError("mode must be 'sparse' or 'dense'")
@@ -105,7 +105,13 @@ class FusedTrainer:
         self.has_fm = kind in ("fm", "deepfm")
         self.lrm = getattr(model, "lr_layer", None) or getattr(model, "wide", None) if self.has_lr else None
         stack = getattr(model, "deep", None) or getattr(model, "mlp", None)
-        self.blocks: List[MLPBlock] = list(stack) if (stack is not None and kind in ("deepfm", "dnn", "widedeep")) else []
+        self.blocks: List[MLPBlock] = list(stack) if (stack is not None and kind in ("deepfm", "dnn", "widedeep", "dcn")) else []
+        # DCN (model/DCN/DCN.py:48-52): the cross network beside the tower on the flattened embeddings, a 1-wide Linear
+        # over [cross output | tower output]
+        self.cross = model.cross if kind == "dcn" else None
+        self.fc2 = model.fc if kind == "dcn" else None
+        if kind == "dcn" and not self.blocks:
+            raise RSError("FusedTrainer: DCN without a deep tower is not scheduled here (use_sparse_step runs it)")
         for b in self.blocks:
             if not isinstance(b, MLPBlock):
                 raise RSError("FusedTrainer: the deep tower must be a stack of MLPBlock")
@@ -175,6 +181,11 @@ class FusedTrainer:
                 ps += [b.norm_layer.weight, b.norm_layer.bias]
             if b._act == ACT_CODES["prelu"]:
                 ps.append(b.activation_func.weight)
+        if self.cross is not None:
+            # w_0 .. w_{L-1}, b_0 .. b_{L-1} side by side ((D, 1) each, D a multiple of 4: no alignment gaps): the cross
+            # kernels read them as [L, D] blocks of the flat buffer and leave (dW, dB) in the same layout
+            ps += list(self.cross.cross_w) + list(self.cross.cross_b)
+            ps += [self.fc2.weight, self.fc2.bias]
         return ps
 
     def _flatten_dense(self):
@@ -376,9 +387,30 @@ class FusedTrainer:
                 if self._drops(b) and not c.drop_fused:
                     h = self._dropout(h, b)              # c.h stays the activation before the mask (act' needs it)
             ctx["mlp"] = cs
-            if h is not None:
+            if self.cross is not None:
+                x0 = r["emb"].view(B, self.F * self.d)
+                w_all, b_all = self._cross_params()
+                xo, sx = ops.dcn_cross_fwd(x0, w_all, b_all)
+                logit = ops.rowdot2_fwd(xo, h, self.fc2.weight.data.view(-1), self.fc2.bias.data, 0)
+                ctx["dcn"] = (x0, xo, sx, h)
+                parts.append(logit)
+            elif h is not None:
                 parts.append(h.view(B))
         return parts, ctx
+
+    def _cross_params(self):
+        """(w [L, D], b [L, D]) of the cross network as blocks of the flat weight buffer, and where their gradients go."""
+        L = self.cross.cross_layers_num
+        D = self.cross.input_dim
+        w0 = self.cross.cross_w[0].data
+        off = (w0.data_ptr() - self.flat_w.data_ptr()) // 4
+        blk = self.flat_w[off:off + 2 * L * D]
+        return blk[:L * D].view(L, D), blk[L * D:].view(L, D)
+
+    def _cross_grad_block(self):
+        L, D = self.cross.cross_layers_num, self.cross.input_dim
+        off = (self.cross.cross_w[0].data.data_ptr() - self.flat_w.data_ptr()) // 4
+        return self.flat_g[off:off + 2 * L * D]
 
     # ---- embedding hooks (overridden by the row-sharded multi-GPU trainer) -----------------------
     def _embed_catch_up(self, idx, mark_ahead: int):
@@ -550,8 +582,11 @@ class FusedTrainer:
                                     sum_dzh_out=self.gviews[id(lastb.fc.bias)], defer=csp)
             parts = parts + [head["h"]]
         else:
+            # (the batch sum of dL/dlogit is the bias gradient of whatever adds a scalar bias to the logit: the LR layer,
+            #  or DCN's last Linear)
             head = ops.bce_head(parts, labels, want_dz=True, grad_scale=self._grad_scale(),
-                                sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr else None)
+                                sum_dz_out=self.gviews[id(self.lrm.bias)] if self.has_lr
+                                else self.gviews[id(self.fc2.bias)] if self.fc2 is not None else None)
         loss, dz = head["loss"], head["dz"]
         keep += [parts, ctx, head]
 
@@ -578,6 +613,18 @@ class FusedTrainer:
             # a block's dW and dX need only its dZ and nothing reads either before the next launch: one launch for both
             grp = ops.GemmGroup(self.group_gemms) if (skp is not None and self.group_gemms) else None
             db_done = False              # the bias gradient of the block about to be visited is already on its way
+            dxo = None
+            if self.cross is not None:
+                # backward of Linear(D + h, 1) over [cross output | tower output]: the cross branch's gradient, the tower's
+                # (with act' of its last block, whose bias gradient then comes out of the same launch) and dW
+                x0, xo, sx, hdeep = ctx["dcn"]
+                lastd = self.blocks[top]
+                fuse_last = (not lastd.normalization and lastd._act in (1, 2, 3) and not self._drops(lastd))
+                dxo, dh = ops.head2_bwd(dz, self.fc2.weight.data.view(-1), xo, hdeep, lastd._act if fuse_last else 0, csp,
+                                        dW_out=self.gviews[id(self.fc2.weight)].view(-1),
+                                        dbp_out=self.gviews[id(lastd.fc.bias)] if fuse_last else None)
+                dz_ready = db_done = fuse_last
+                keep.append(dxo)
             if head_fast:
                 _, xin, _ = cs[top]
                 prev = self.blocks[top - 1] if top > 0 else None
@@ -659,6 +706,15 @@ class FusedTrainer:
                     dh = self._dropout(dh, prev)         # this block read the masked activation of the previous one
                 dz_ready = fuse_prev
                 keep.append(dh)
+            if self.cross is not None:
+                # the cross network's backward: its share of the embeddings' gradient and (dW, dB) as partial rows whose
+                # sums join the step's one finishing launch
+                x0, xo, sx, hdeep = ctx["dcn"]
+                w_all, b_all = self._cross_params()
+                dtower = dh
+                dh, _, _ = ops.dcn_cross_bwd(x0, sx, dxo, w_all, b_all, g_out=self._cross_grad_block(), parts=csp,
+                                             dx_add=dtower.view(B, self.F * self.d))
+                keep += [dtower, dh]
             # the bias-gradient finishes and the weight-gradient split-K reduces: beside the first launch of the
             # embedding reduction when that is fused
             carry = self._reduce_carries_finishes and not overlap and self.mode == "sparse"

@@ -1484,16 +1484,22 @@ def dcn_cross_fwd(x0: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     return out, S
 
 
-def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None, parts: "ColsumParts" = None):
-    """-> (dx0 [B,D], dW [L,D], dB [L,D]); g_out: optional [2*L*D] destination of (dW, dB) laid end to end."""
+def dcn_cross_bwd(x0, S, dout, w, bias, g_out=None, parts: "ColsumParts" = None, dx_add=None):
+    """-> (dx0 [B,D], dW [L,D], dB [L,D]); g_out: optional [2*L*D] destination of (dW, dB) laid end to end; dx_add [B,D]:
+    added into dx0 (the gradient x0 receives from elsewhere)."""
     B, D = x0.shape
     L = w.shape[0]
     _chk(dout, torch.float32, "dout", (B, D))
     _chk(g_out, torch.float32, "g_out", (2 * L * D,))
+    _chk(dx_add, torch.float32, "dx_add", (B, D))
     rows = interact_partial_rows(B)
     dx0 = torch.empty_like(x0)
     part = torch.empty((rows, 2 * L * D), dtype=torch.float32, device=x0.device)
-    call("rs_dcn_cross_bwd", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx0), ptr(part), rows, stream())
+    if dx_add is not None:
+        call("rs_dcn_cross_bwd_add", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx_add), ptr(dx0), ptr(part),
+             rows, stream())
+    else:
+        call("rs_dcn_cross_bwd", ptr(x0), ptr(S), ptr(dout), ptr(w), ptr(bias), B, D, L, ptr(dx0), ptr(part), rows, stream())
     g = colsum(part, out=g_out, parts=parts if g_out is not None else None)     # with parts: valid after its finish()
     return dx0, g[:L * D].view(L, D), g[L * D:].view(L, D)
 

@@ -121,3 +121,39 @@ def test_ffm_step_at_criteo_shape(optimizer, use_graph):
         assert int(loose.sum()) <= max(1, diff.numel() // 200000), f"{k}: {int(loose.sum())} of {diff.numel()} elements off"
         assert float(diff.max()) <= 3e-4, f"{k}: greatest difference {float(diff.max())}"
     assert eng.step_count.item() == steps
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("optimizer,kw", [
+    ("SGD", dict(hidden_dim_list=[32, 16], cross_layers_num=3, normalization=None)),
+    ("Adam", dict(hidden_dim_list=[32, 16], cross_layers_num=2, normalization=None)),
+    ("AdamW", dict(hidden_dim_list=[32, 16], cross_layers_num=3, normalization=None, activation_func="tanh")),
+    ("SGD", dict(hidden_dim_list=[32, 16], cross_layers_num=2, normalization="bn")),
+    ("Adam", dict(hidden_dim_list=[32], cross_layers_num=1, normalization="ln")),
+], ids=["sgd", "adam", "adamw-tanh", "sgd-bn", "adam-ln"])
+def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
+    """DCN (model/DCN/DCN.py:48-52) on the hand-scheduled step (engine.FusedTrainer: cross network forward / backward,
+    the two-block 1-wide head with the tower's last act' fused, everything else as for DeepFM) against the CPU oracle's
+    dense torch step, as the generic trainer is checked above."""
+    m, rec = build("dcn", "SGD", **kw)
+    o = make_oracle("dcn", m, rec, kw)
+    eng = m.use_fused_step(mode="sparse", optimizer_type=optimizer, lr=1e-2, use_graph=graph)
+    opt = O.make_optimizer(optimizer, o.parameters(), 1e-2)
+    g = torch.Generator().manual_seed(123)
+    steps = 3
+    for step in range(steps):
+        x = {c: (torch.rand(BATCH, generator=g) ** 2 * v).long().clamp(0, v - 1) for c, v in zip(rec.features, VOCAB)}
+        y = (torch.rand(BATCH, generator=g) < 0.4).long()
+        loss = m.train_step(x, {"label": y})
+        ref_loss, _ = O.train_step(o, opt, x, y)
+        torch.testing.assert_close(loss.cpu().view(()), ref_loss.view(()), rtol=2e-5, atol=1e-6)
+        osd = o.state_dict()
+        for k, v in m.state_dict().items():
+            ok = key_to_oracle(k, "dcn")
+            if ok is None or not v.dtype.is_floating_point or noise_driven("dcn", kw, k):
+                continue
+            if kw.get("normalization") == "bn" and k.endswith(".fc.bias") and k.startswith("deep."):
+                continue            # in front of a BatchNorm: gradient exactly zero, noise on both sides
+            atol = 5e-5 if optimizer in ("Adam", "AdamW") else 5e-6
+            torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
+    assert eng.step_count.item() == steps
