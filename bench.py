@@ -292,7 +292,9 @@ def main():
 
     model, rec, hidden = build(args, device)
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
-    fused_kind = getattr(model, "KIND", None) in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn")
+    kind = getattr(model, "KIND", None)
+    fused_kind = kind in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn") or (
+        kind == "pnn" and model.pnn_type == "inner" and not use_dist)
     if use_dist and fused_kind:
         from recommendsystem_amd.dist import DistributedTrainer, ReplicatedTablesTrainer
         cls = ReplicatedTablesTrainer if args.tables == "replicated" else DistributedTrainer

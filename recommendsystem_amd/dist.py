@@ -509,8 +509,8 @@ class DistributedTrainer(FusedTrainer):
                  bucket_slack: float = 1.5, overlap_comm: Optional[bool] = None, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
-        if getattr(model, "KIND", None) == "dcn":
-            raise RSError("DistributedTrainer: DCN runs on several GPUs through DistributedSparseTrainer")
+        if getattr(model, "KIND", None) in ("dcn", "pnn"):
+            raise RSError("DistributedTrainer: DCN and PNN run on several GPUs through DistributedSparseTrainer")
         if use_graph and stage_cpu:
             raise RSError("DistributedTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)

@@ -74,7 +74,12 @@ class FusedTrainer:
         model/utils/BaseModel.py:64-72)."""
         self.betas = (float(betas[0]), float(betas[1]))
         kind = getattr(model, "KIND", None)
-        if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn"):
+        if kind == "pnn" and not (getattr(model, "pnn_type", None) == "inner"
+                                   and ops.pnn_inner_cat_ok(len(model.embedding_layer.lookup_columns),
+                                                            model.embedding_layer.embedding_dim)):
+            raise RSError("FusedTrainer: of the PNN variants only pnn_type='inner' is scheduled here "
+                          "(use_sparse_step runs the others)")
+        if kind not in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn", "pnn"):
             raise RSError(f"FusedTrainer: model kind {kind!r} is not covered by the fused step")
         if mode not in ("sparse", "dense"):
             raise ValueError("mode must be 'sparse' or 'dense'")
@@ -105,7 +110,9 @@ class FusedTrainer:
         self.has_fm = kind in ("fm", "deepfm")
         self.lrm = getattr(model, "lr_layer", None) or getattr(model, "wide", None) if self.has_lr else None
         stack = getattr(model, "deep", None) or getattr(model, "mlp", None)
-        self.blocks: List[MLPBlock] = list(stack) if (stack is not None and kind in ("deepfm", "dnn", "widedeep", "dcn")) else []
+        self.blocks: List[MLPBlock] = list(stack) if (stack is not None and kind in ("deepfm", "dnn", "widedeep", "dcn", "pnn")) else []
+        # PNN with inner products (model/PNN/PNN.py:58,80-89): the tower reads [embeddings | <e_i, e_j> of all pairs]
+        self.pnn_inner = kind == "pnn"
         # DCN (model/DCN/DCN.py:48-52): the cross network beside the tower on the flattened embeddings, a 1-wide Linear
         # over [cross output | tower output]
         self.cross = model.cross if kind == "dcn" else None
@@ -193,11 +200,21 @@ class FusedTrainer:
         the nn.Parameters become views into it."""
         ps = self._dense_params()
         n = sum(p.numel() for p in ps)
+        # A weight whose rows are not a multiple of four floats long (PNN-inner's first layer: F*d + F(F-1)/2 inputs) is
+        # kept with its rows padded to the next multiple: the padding columns are zero, receive zero gradients and stay
+        # zero under every optimizer here, the parameter itself is the strided view without them, and the GEMMs take the
+        # padded block (aligned rows) together with an input whose padding columns are zero as well.
+        self._wfull, self._gfull = {}, {}
+        padded = {}
+        if getattr(self, "pnn_inner", False) and self.blocks:
+            w0 = self.blocks[0].fc.weight
+            if w0.shape[1] % 4:
+                padded[id(w0)] = (w0.shape[0], w0.shape[1], (w0.shape[1] + 3) // 4 * 4)
         # keep every view 16-byte aligned so the GEMM loaders can use 16-byte loads
         offs, o = [], 0
         for p in ps:
             offs.append(o)
-            o += (p.numel() + 3) // 4 * 4
+            o += padded[id(p)][0] * padded[id(p)][2] if id(p) in padded else (p.numel() + 3) // 4 * 4
         self.flat_w = torch.zeros(max(o, 4), dtype=torch.float32, device=self.device)
         # four spare floats behind the gradients: the multi-GPU trainer sends its scalar reductions along
         # with the one all-reduce of this buffer
@@ -206,11 +223,30 @@ class FusedTrainer:
         self.gviews = {}
         with torch.no_grad():
             for p, off in zip(ps, offs):
+                if id(p) in padded:
+                    rows, k, ld = padded[id(p)]
+                    full = self.flat_w[off:off + rows * ld].view(rows, ld)
+                    full[:, :k].copy_(p.data)
+                    p.data = full[:, :k]
+                    gfull = self.flat_g[off:off + rows * ld].view(rows, ld)
+                    self._wfull[id(p)], self._gfull[id(p)] = full, gfull
+                    self.gviews[id(p)] = gfull[:, :k]
+                    continue
                 v = self.flat_w[off:off + p.numel()].view_as(p)
                 v.copy_(p.data)
                 p.data = v
                 self.gviews[id(p)] = self.flat_g[off:off + p.numel()].view_as(p)
         self.n_dense = o
+
+    def _w(self, b):
+        """The weight block the GEMMs of block b read (rows padded to a multiple of four floats where the parameter's
+        are not) and where its gradient goes."""
+        p = b.fc.weight
+        return self._wfull.get(id(p), p.data)
+
+    def _gw(self, b):
+        p = b.fc.weight
+        return self._gfull.get(id(p), self.gviews[id(p)])
 
     def _alloc_state(self):
         dev = self.device
@@ -358,7 +394,8 @@ class FusedTrainer:
         if self.has_fm:
             parts.append(r["fm"])
         if self.blocks:
-            h = r["emb"].view(B, self.F * self.d)
+            # PNN-inner: one launch writes [embeddings | inner products | zeros up to a multiple of four columns]
+            h = ops.pnn_inner_cat_fwd(r["emb"]) if self.pnn_inner else r["emb"].view(B, self.F * self.d)
             cs = []
             for bi, b in enumerate(self.blocks):
                 if bi == len(self.blocks) - 1 and self._head_fast:
@@ -380,7 +417,7 @@ class FusedTrainer:
                         rm, rv = b.norm_layer.running_mean, b.norm_layer.running_var
                 if b._act == ACT_CODES["prelu"]:
                     slope = b.activation_func.weight.data
-                h, c = Fn.mlp_block_fwd(h, b.fc.weight.data, b.fc.bias.data, b._act, b.normalization or None, gamma,
+                h, c = Fn.mlp_block_fwd(h, self._w(b), b.fc.bias.data, b._act, b.normalization or None, gamma,
                                         beta, slope, self.model.training, rm, rv, eps,
                                         dropout=self._drop_key(b) if self._drops(b) else None)
                 cs.append(c)
@@ -657,7 +694,7 @@ class FusedTrainer:
                 if not b.normalization and b._act in _FUSABLE:
                     dzl = dh if (dz_ready or b._act == 0) else ops.act_bwd(dh, b._act, h=c.h)[0]
                     keep.append(dzl)
-                    gW, gb = self.gviews[id(b.fc.weight)], self.gviews[id(b.fc.bias)]
+                    gW, gb = self._gw(b), self.gviews[id(b.fc.bias)]
                     if db_done and grp is not None:
                         grp.add(dzl, c.x, a_mc=True, b_nc=True, out=gW, defer_reduce=skp)
                     elif db_done:
@@ -691,7 +728,7 @@ class FusedTrainer:
                     db_done = fuse_prev
                 else:
                     r = Fn.mlp_block_bwd(dh, c, need_dx=True, dz_ready=dz_ready,
-                                         dW_out=self.gviews[id(b.fc.weight)], db_out=self.gviews[id(b.fc.bias)],
+                                         dW_out=self._gw(b), db_out=self.gviews[id(b.fc.bias)],
                                          mulsrc=cs[i - 1].h if fuse_prev else None, mul_act=prev._act if fuse_prev else 0,
                                          dx_dropout=mask_key)
                     if b.normalization:
@@ -715,6 +752,11 @@ class FusedTrainer:
                 dh, _, _ = ops.dcn_cross_bwd(x0, sx, dxo, w_all, b_all, g_out=self._cross_grad_block(), parts=csp,
                                              dx_add=dtower.view(B, self.F * self.d))
                 keep += [dtower, dh]
+            if self.pnn_inner:
+                # gradient of [embeddings | inner products | pad] -> gradient of the embeddings
+                dcat = dh
+                dh = ops.pnn_inner_cat_bwd(ctx["emb"], dcat)
+                keep += [dcat, dh]
             # the bias-gradient finishes and the weight-gradient split-K reduces: beside the first launch of the
             # embedding reduction when that is fused
             carry = self._reduce_carries_finishes and not overlap and self.mode == "sparse"

@@ -157,3 +157,56 @@ def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
             atol = 5e-5 if optimizer in ("Adam", "AdamW") else 5e-6
             torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
     assert eng.step_count.item() == steps
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("optimizer,kw", [
+    ("SGD", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization=None)),
+    ("Adam", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization=None)),
+    ("AdamW", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization=None, activation_func="tanh")),
+    ("SGD", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization="bn")),
+    ("Adam", dict(hidden_dim_list=[32], pnn_type="inner", normalization="ln")),
+], ids=["sgd", "adam", "adamw-tanh", "sgd-bn", "adam-ln"])
+def test_pnn_inner_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
+    """PNN with inner products (model/PNN/PNN.py:58,80-89) on the hand-scheduled step (engine.FusedTrainer): the tower
+    reads [embeddings | inner products] rows of 63 floats here, kept padded to 64 in the flat weight buffer, so the
+    first layer's weight is a strided view of its padded block.  Checked against the CPU oracle's dense torch step."""
+    m, rec = build("pnn", "SGD", **kw)
+    o = make_oracle("pnn", m, rec, kw)
+    eng = m.use_fused_step(mode="sparse", optimizer_type=optimizer, lr=1e-2, use_graph=graph)
+    w0 = m.mlp[0].fc.weight
+    assert w0.shape[1] == 63 and w0.stride(0) == 64
+    opt = O.make_optimizer(optimizer, o.parameters(), 1e-2)
+    g = torch.Generator().manual_seed(123)
+    steps = 3
+    for step in range(steps):
+        x = {c: (torch.rand(BATCH, generator=g) ** 2 * v).long().clamp(0, v - 1) for c, v in zip(rec.features, VOCAB)}
+        y = (torch.rand(BATCH, generator=g) < 0.4).long()
+        loss = m.train_step(x, {"label": y})
+        ref_loss, _ = O.train_step(o, opt, x, y)
+        torch.testing.assert_close(loss.cpu().view(()), ref_loss.view(()), rtol=2e-5, atol=1e-6)
+        osd = o.state_dict()
+        for k, v in m.state_dict().items():
+            ok = key_to_oracle(k, "pnn")
+            if ok is None or not v.dtype.is_floating_point:
+                continue
+            if kw.get("normalization") == "bn" and k.endswith(".fc.bias"):
+                continue            # in front of a BatchNorm: gradient exactly zero, noise on both sides
+            atol = 5e-5 if optimizer in ("Adam", "AdamW") else 5e-6
+            torch.testing.assert_close(v.cpu(), osd[ok], rtol=1e-4, atol=atol, msg=lambda s, k=k: f"{k} after step {step}: {s}")
+    assert eng.step_count.item() == steps
+    # the pad column of the first layer's block stays zero under every optimizer
+    full = eng._wfull[id(w0)]
+    assert float(full[:, 63:].abs().max()) == 0.0
+    # evaluation runs the model's own forward on the strided weight
+    m.eval()
+    o.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(m.logits(x).cpu().view(-1), o(x).view(-1), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_engine_refuses_other_pnn_variants():
+    from recommendsystem_amd._lib import RSError
+    m, _ = build("pnn", "SGD", hidden_dim_list=[32, 16], pnn_type="outer", normalization=None)
+    with pytest.raises(RSError):
+        m.use_fused_step(mode="sparse")
