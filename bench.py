@@ -42,6 +42,10 @@ def parse():
                    help="39 = 13 small-vocabulary + 26 categorical fields; 26 = the categorical fields only")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
+    p.add_argument("--regular", type=float, default=0.0,
+                   help="emb_regular = net_regular (BaseModel.py:214-231); with --optimizer SGD the touched-rows step "
+                        "carries the tables' shrink in one scalar, other optimizers need --mode dense; not part of "
+                        "the CPU baseline (use --cpu-baseline 0)")
     p.add_argument("--activation", type=str, default="ReLU",
                    help="activation of the MLP blocks (the reference's default ReLU also sits on the 1-wide last block)")
     p.add_argument("--dropout", type=float, default=0.0,
@@ -107,6 +111,8 @@ def build(args, device):
     hidden = [int(h) for h in args.hidden.split(",") if h]
     gpu = device.index
     kw = dict(optimizer_type=args.optimizer)
+    if args.regular > 0:
+        kw["regular"] = args.regular
     if args.model in ("deepfm", "dnn", "widedeep", "pnn", "pnn_inner", "dcn", "nfm"):
         kw["activation_func"] = args.activation
         if args.dropout > 0:
@@ -551,6 +557,7 @@ def main():
                                    + f", embedding_dim {args.dim}, MLP {hidden}, per-GPU batch {args.batch}",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "fields": len(vocab),
                        "embedding_dim": args.dim, "hidden": hidden, "optimizer": args.optimizer, "dropout": args.dropout,
+                       "regular": args.regular,
                        "embedding_update": args.mode if args.mode == "dense" or args.optimizer not in ("Adam", "AdamW")
                        else ("sparse, exact: touched rows only, a row's skipped zero-gradient steps replayed before it is read "
                              "(the reference's dense optimizer)" if getattr(eng, "exact", False)

@@ -54,6 +54,15 @@ int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int
                         const float* table1, const float* bias, float* emb_out, float* sum_out, float* bi_out,
                         float* lr_out, float* fm_out, int B, int F, int d, int* err_flag, rs_stream_t stream);
 
+/* rs_gather_lr_fm_fwd on tables kept as w / *scale (scale: one float in device memory; null = 1): every looked-up
+ * value, and through them the sums, the LR logit without its bias and the FM term, is that of the table times *scale.
+ * For trainers that apply the per-step shrink of the L2 term (BaseModel.py:214-231 under SGD: every row of every
+ * nn.Embedding is multiplied by 1 - lr c lambda per step) to one scalar instead of every row. */
+int rs_gather_lr_fm_fwd_scaled(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab, const float* table,
+                               const float* table1, const float* bias, float* emb_out, float* sum_out, float* bi_out,
+                               float* lr_out, float* fm_out, int B, int F, int d, const float* scale, int* err_flag,
+                               rs_stream_t stream);
+
 /* ---- K2e: MLP GEMMs on the matrix cores (fp32 in, fp32 accumulate) --------------------------- */
 /* C[M,N] = epi(op(A) op(B)),  epi(v) = act(v + bias[n]) * act'(mulsrc[m,n]) (each part optional).
  * a_mc = 0: A is [M,K] row-major; 1: A is stored [K,M].  b_nc = 0: B is [N,K] (nn.Linear weight);
@@ -442,6 +451,28 @@ int rs_clip_coef(const float* partials, int n, float max_norm, float* scal, rs_s
 int rs_opt_prepare(long long* step, float* hyper, rs_stream_t stream);
 int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* scal, long long* step, float* hyper,
                         rs_stream_t stream);
+
+/* ---- SGD with emb_regular on tables that are stepped on touched rows only -------------------------------------
+ * BaseModel.regularization_loss (model/utils/BaseModel.py:214-231) adds lambda/2 ||W||^2 of every nn.Embedding to the
+ * loss; under torch.optim.SGD (BaseModel.py:64-72) behind clip_grad_norm_ (:148) every row then has the gradient
+ * g_r + lambda w_r, counts in the clipped norm, and rows the batch does not touch shrink by s = 1 - lr c lambda.
+ * The tables are kept as w / G with one scalar G for all of them, so that shrink is G' = G s and no row is visited:
+ *   rs_sparse_touched_dot: partials [F * rs_sparse_touched_dot_groups(cap, d)] = per-workgroup sums of
+ *     <rowgrad[f, u, :], table[seg_row[f, u], :]> (+ rowgrad1 * table1) over the distinct rows of the plan;
+ *   rs_clip_and_prepare_l2 = rs_clip_and_prepare with
+ *     norm^2 = sum partials[n_sparse, n) + A + 2 lambda B + lambda^2 S,   A = sum partials[0, n_sparse) (the touched
+ *     rows' ||g_r||^2), B = G * sum dot_partials, state = {G, S = sum ||w||^2 over every row of every table} (double);
+ *     it leaves scal = {norm, c}, scal_tab = {norm, c / G'} (rs_sparse_update with SGD on the stored rows then is the
+ *     reference's step w' = s w - lr c g), gscale = (float)G' for rs_gather_lr_fm_fwd_scaled, state = {G', S'} with
+ *     S' = s^2 S - 2 s lr c B + lr^2 c^2 A, and adds lambda/2 S to *loss (optional);
+ *   rs_scale_inplace: x *= (float)*scale -- turns stored rows back into weights (before a checkpoint / evaluation). */
+int rs_sparse_touched_dot_groups(int cap, int d);
+int rs_sparse_touched_dot(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,
+                          const float* table, const float* table1, float* partials, int n_partials, rs_stream_t stream);
+int rs_clip_and_prepare_l2(const float* partials, int n_sparse, int n, const float* dot_partials, int n_dot,
+                           float max_norm, float emb_l2, double* state, float* scal, float* scal_tab, float* gscale,
+                           float* loss, long long* step, float* hyper, rs_stream_t stream);
+int rs_scale_inplace(float* x, long long n, const double* scale, rs_stream_t stream);
 
 /* ---- dense Adam / AdamW semantics on tables that are stepped on touched rows only ---------------------------
  * torch.optim.Adam / AdamW as the reference builds them (model/utils/BaseModel.py:64-72) step EVERY row of every

@@ -374,9 +374,21 @@ def gen_state_dict_layout():
         json.dump(layout, f, indent=1)
 
 
+def gen_train_reg_sgd():
+    """SGD with the L2 term on every nn.Embedding (BaseModel.py:214-231): every table row shrinks in every step.
+    The third trace has a lambda large enough for lambda * ||W|| to exceed max_norm = 10, so clip_grad_norm_ bites and
+    the shrink factor changes from step to step."""
+    gen_train("lr", "SGD", 1e-2, "train_lr_sgd_reg.npz", scale_tables=1000.0, lr=0.05, steps=4)
+    gen_train("deepfm", "SGD", 1e-3, "train_deepfm_sgd_reg.npz", hidden=(16, 8), scale_tables=1000.0, lr=0.05, steps=4)
+    gen_train("fm", "SGD", 4.0, "train_fm_sgd_reg_clip.npz", scale_tables=1000.0, lr=0.02, steps=4)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
+    if sys.argv[1:] == ["reg_sgd"]:          # only the fixtures of gen_train_reg_sgd (the others stay as committed)
+        gen_train_reg_sgd()
+        sys.exit(0)
     gen_layers()
     gen_mlp()
     gen_interactions()
@@ -396,6 +408,7 @@ if __name__ == "__main__":
               bs=8, slim=True)
     gen_train("deepfm", "AdamW", None, "train_deepfm_adamw_long.npz", hidden=(16, 8), scale_tables=1000.0, steps=8,
               bs=8, slim=True)
+    gen_train_reg_sgd()
     gen_state_dict_layout()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes:", tot, sorted(os.listdir(OUT)))

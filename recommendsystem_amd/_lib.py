@@ -45,6 +45,8 @@ _SIGS = {
     "rs_gather_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
     "rs_gather_lr_fm_fwd": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p,
                             c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_i32p, c_stream],
+    "rs_gather_lr_fm_fwd_scaled": [c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p,
+                                   c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, I, I, c_f32p, c_i32p, c_stream],
     # gemm.hip
     "rs_gemm_f32": [I, I, I, I, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, c_f32p, I, I,
                     I, I, c_f32p, SZ, c_f32p, c_stream],
@@ -85,6 +87,10 @@ _SIGS = {
     "rs_clip_coef": [c_f32p, I, F, c_f32p, c_stream],
     "rs_opt_prepare": [c_i64p, c_f32p, c_stream],
     "rs_clip_and_prepare": [c_f32p, I, F, c_f32p, c_i64p, c_f32p, c_stream],
+    "rs_sparse_touched_dot": [c_i32p, I, I, I, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, I, c_stream],
+    "rs_clip_and_prepare_l2": [c_f32p, I, I, c_f32p, I, F, F, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p,
+                               c_f32p, c_stream],
+    "rs_scale_inplace": [c_f32p, L, C.c_void_p, c_stream],
     # rowstate.hip
     "rs_adam_bc_table": [c_f32p, I, c_f32p, c_stream],
     "rs_adam_catchup": [c_i64p, c_i64p, c_i64p, I, I, I, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p,
@@ -186,6 +192,7 @@ _PLAIN = {
     "rs_sort_split_max_entries": (I, []),
     "rs_sparse_bwd_num_partials": (I, [I, I, I]),
     "rs_sparse_window": (I, [I]),
+    "rs_sparse_touched_dot_groups": (I, [I, I]),
     "rs_act_bwd_num_partials": (I, [L]),
     "rs_interact_partial_rows": (I, [I]),
     "rs_ffm_bwd_num_partials": (I, [I, I]),

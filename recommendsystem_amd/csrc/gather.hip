@@ -26,10 +26,26 @@ extern "C" {
 
 // Fused gather.  Any of the outputs may be null; `table` may be null when only the 1-dim
 // (LR) path is wanted, `table1` may be null when only embeddings are wanted.
+int rs_gather_lr_fm_fwd_scaled(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab,
+                               const float* table, const float* table1, const float* bias,
+                               float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out,
+                               int B, int F, int d, const float* scale, int* err_flag, hipStream_t stream);
+
 int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab,
                         const float* table, const float* table1, const float* bias,
                         float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out,
                         int B, int F, int d, int* err_flag, hipStream_t stream) {
+    return rs_gather_lr_fm_fwd_scaled(idx, row_offset, vocab, table, table1, bias, emb_out, sum_out, bi_out, lr_out,
+                                      fm_out, B, F, d, nullptr, err_flag, stream);
+}
+
+// rs_gather_lr_fm_fwd on tables kept as w / *scale (scale: a device scalar, null = 1): every looked-up value -- rows,
+// 1-dim weights, and through them the sums and the FM term -- is that of the table times *scale.  The bias is not
+// scaled.
+int rs_gather_lr_fm_fwd_scaled(const int64_t* idx, const int64_t* row_offset, const int64_t* vocab,
+                               const float* table, const float* table1, const float* bias,
+                               float* emb_out, float* sum_out, float* bi_out, float* lr_out, float* fm_out,
+                               int B, int F, int d, const float* scale, int* err_flag, hipStream_t stream) {
     if (B == 0) return RS_OK;
     RS_CHECK_ARG(idx && row_offset && vocab, "rs_gather_lr_fm_fwd: null index arguments");
     RS_CHECK_ARG(B >= 0 && F > 0 && d > 0, "rs_gather_lr_fm_fwd: bad sizes B=%d F=%d d=%d", B, F, d);
@@ -40,6 +56,7 @@ int rs_gather_lr_fm_fwd(const int64_t* idx, const int64_t* row_offset, const int
     if (B == 0) return RS_OK;
     GatherArgs a{idx, row_offset, vocab, table, table1, bias, emb_out, sum_out, bi_out, lr_out, fm_out,
                  err_flag, B, F, d, 1, 1};
+    a.scale = scale;
     int VEC = 1;
     if (!table) { VEC = 1; a.C = 1; a.G = 8; a.d = 1; }
     else RS_CHECK_ARG(pick_layout(d, &VEC, &a.G, &a.C) == 0,

@@ -24,6 +24,9 @@ struct GatherArgs {
     // ld floats between rows and `table1` at its 1-dim column with ld1 floats between rows.
     const int* slots;
     int ld, ld1;
+    // device scalar every looked-up value is multiplied by (null: none): tables kept as w / scale by a trainer that
+    // applies a per-step shrink of ALL rows (L2 regularisation under SGD) to the scalar instead of the rows
+    const float* scale;
 };
 
 template <int VEC> struct VecT;
@@ -70,6 +73,7 @@ __device__ __forceinline__ void gather_fused_body(const GatherArgs& a, int wave)
     for (int e = 0; e < VEC; ++e) { acc[e] = 0.f; accq[e] = 0.f; }
     float lr = 0.f;
     bool bad = false;
+    const float sc = a.scale ? *a.scale : 1.f;
 
     const int iters = (a.F + a.G - 1) / a.G;
     for (int i0 = 0; i0 < iters; i0 += U) {
@@ -103,6 +107,14 @@ __device__ __forceinline__ void gather_fused_body(const GatherArgs& a, int wave)
                     if (a.table) vload<VEC>(a.table + row[u] * d + c * VEC, v[u]);
                     if (a.table1 && c == 0) w1[u] = a.table1[row[u]];
                 }
+            }
+        }
+        if (a.scale) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[u][e] *= sc;
+                w1[u] *= sc;
             }
         }
 #pragma unroll

@@ -740,6 +740,42 @@ __global__ __launch_bounds__(256) void scatter_rowgrad_kernel(UpdateArgs a) {
     if (cc == 0 && a.table1) a.table1[row] = a.rowgrad1[(long long)f * a.cap + u];
 }
 
+// sum over the touched rows of <reduced gradient, stored row> (both tables), one partial per workgroup: what the L2
+// term of a table contributes to the squared gradient norm beyond ||g||^2 and lambda^2 ||W||^2
+constexpr int DOT_GROUPS = 32;
+template <int VEC>
+__global__ __launch_bounds__(256) void touched_dot_kernel(UpdateArgs a, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int f = blockIdx.y;
+    const int grp = threadIdx.x / a.C, cc = threadIdx.x - grp * a.C;
+    const int gpb = 256 / a.C;
+    const int n = a.counts[f * 4 + 2];
+    const int d = a.d, co = cc * VEC;
+    float s = 0.f;
+    if (grp < gpb) {
+        for (int u = blockIdx.x * gpb + grp; u < n; u += gridDim.x * gpb) {
+            const long long row = a.seg_row[(long long)f * a.cap + u];
+            if (a.table) {
+                float g[VEC], w[VEC];
+                ldv<VEC>(a.rowgrad + ((long long)f * a.cap + u) * d + co, g);
+                ldv<VEC>(a.table + row * d + co, w);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s = fmaf(g[e], w[e], s);
+            }
+            if (cc == 0 && a.table1) s = fmaf(a.rowgrad1[(long long)f * a.cap + u], a.table1[row], s);
+        }
+    }
+    const float tot = rs_block_sum<256>(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+// x *= *scale (a device scalar held in double precision)
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ x, long long n, const double* __restrict__ scale) {
+    const float sc = (float)*scale;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= sc;
+}
+
 // dense flat-buffer optimizer step (MLP towers, biases): one launch over all dense parameters
 __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                            float* m, float* v, long long n, int opt,
@@ -814,6 +850,55 @@ __global__ __launch_bounds__(1024) void clip_prepare_kernel(const float* __restr
         scal[0] = nrm;
         float c = max_norm / (nrm + 1e-6f);
         scal[1] = (max_norm > 0.f && c < 1.f) ? c : 1.f;
+        const long long t = *step + 1;
+        *step = t;
+        const double b1 = (double)hyper[1], b2 = (double)hyper[2];
+        const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+        hyper[5] = (float)((double)hyper[0] / bc1);
+        hyper[6] = (float)sqrt(bc2);
+    }
+}
+
+// clip_prepare_kernel for SGD with an L2 term lambda/2 ||W||^2 over tables that are stepped on touched rows only and
+// kept as w / G.  partials[0, n_sparse): ||g_r||^2 of the touched rows (A); partials[n_sparse, n): the dense part;
+// dot[0, n_dot): <g_r, stored row> (times G: B = sum <g_r, w_r>).  state[0] = G, state[1] = S = sum ||w||^2 over all
+// rows of all tables.  With every row's gradient g_r + lambda w_r (g_r = 0 off the batch):
+//   norm^2 = dense + A + 2 lambda B + lambda^2 S,  c = clip coefficient,  s = 1 - lr c lambda (what a row without
+//   data gradient is multiplied by),  G' = G s,  S' = s^2 S - 2 s lr c B + lr^2 c^2 A.
+// A touched row's step w' = s w - lr c g is, on the stored row, w'/G' = w/G - (lr c / G') g: the plain SGD step with
+// the coefficient scal_tab[1] = c / G'.  gscale = (float)G' is what the next lookup multiplies by.
+__global__ __launch_bounds__(1024) void clip_prepare_l2_kernel(const float* __restrict__ partials, int n_sparse, int n,
+                                                               const float* __restrict__ dot, int n_dot, float max_norm,
+                                                               float lambda, double* __restrict__ state,
+                                                               float* __restrict__ scal, float* __restrict__ scal_tab,
+                                                               float* __restrict__ gscale, float* loss, long long* step,
+                                                               float* hyper) {
+    __shared__ float red[16];
+    const float A = sum_partials_1024(partials, n_sparse, red);
+    __syncthreads();
+    const float Dn = sum_partials_1024(partials + n_sparse, n - n_sparse, red);
+    __syncthreads();
+    const float Bs = sum_partials_1024(dot, n_dot, red);
+    if (threadIdx.x == 0) {
+        const double G = state[0], S = state[1], lam = (double)lambda, lr = (double)hyper[0];
+        const double Bq = G * (double)Bs;
+        double n2 = (double)Dn + (double)A + 2.0 * lam * Bq + lam * lam * S;
+        if (n2 < 0.0) n2 = 0.0;
+        const float nrm = (float)sqrt(n2);
+        scal[0] = nrm;
+        float c = max_norm / (nrm + 1e-6f);
+        c = (max_norm > 0.f && c < 1.f) ? c : 1.f;
+        scal[1] = c;
+        const double s = 1.0 - lr * (double)c * lam;
+        const double Gn = G * s;
+        double Sn = s * s * S - 2.0 * s * lr * (double)c * Bq + lr * lr * (double)c * (double)c * (double)A;
+        if (Sn < 0.0) Sn = 0.0;
+        state[0] = Gn;
+        state[1] = Sn;
+        scal_tab[0] = nrm;
+        scal_tab[1] = (float)((double)c / Gn);
+        gscale[0] = (float)Gn;
+        if (loss) loss[0] += (float)(0.5 * lam * S);
         const long long t = *step + 1;
         *step = t;
         const double b1 = (double)hyper[1], b2 = (double)hyper[2];
@@ -1502,6 +1587,65 @@ int rs_clip_and_prepare(const float* partials, int n, float max_norm, float* sca
     return RS_OK;
 }
 
+// ---- SGD with an L2 term on tables that are stepped on touched rows only (model/utils/BaseModel.py:214-231: the
+// reference adds lambda/2 ||W||^2 of every nn.Embedding to the loss, so every row has the gradient lambda w, is part of
+// the clipped norm and shrinks in every step).  The tables are kept as w / G with one device scalar G for all of them.
+
+// Workgroups per field of rs_sparse_touched_dot (its partials: F times that many floats).
+int rs_sparse_touched_dot_groups(int cap, int d) {
+    int VEC, C;
+    if (cap <= 0 || lanes_wide(d, &VEC, &C) != 0) return -1;
+    const int gx = rs_cdiv(cap, 256 / C);
+    return gx < DOT_GROUPS ? gx : DOT_GROUPS;
+}
+
+// partials[F * groups] = per-workgroup sums of <rowgrad[f, u, :], table[seg_row[f, u], :]> (+ rowgrad1 * table1) over
+// the distinct rows of the plan.
+int rs_sparse_touched_dot(const int* plan, int F, int cap, int d, const float* rowgrad, const float* rowgrad1,
+                          const float* table, const float* table1, float* partials, int n_partials, hipStream_t stream) {
+    RS_CHECK_ARG(plan && partials, "rs_sparse_touched_dot: null argument");
+    RS_CHECK_ARG(!table || rowgrad, "rs_sparse_touched_dot: table without rowgrad");
+    RS_CHECK_ARG(!table1 || rowgrad1, "rs_sparse_touched_dot: table1 without rowgrad1");
+    UpdateArgs a{};
+    int VEC;
+    RS_CHECK_ARG(fill_update(a, plan, F, cap, d, &VEC) == 0, "rs_sparse_touched_dot: unsupported d=%d", d);
+    const int gx = rs_sparse_touched_dot_groups(cap, d);
+    RS_CHECK_ARG(n_partials == F * gx, "rs_sparse_touched_dot: partials must hold %d floats", F * gx);
+    a.rowgrad = rowgrad; a.rowgrad1 = rowgrad1;
+    a.table = const_cast<float*>(table); a.table1 = const_cast<float*>(table1);
+    dim3 grid(gx, F), block(256);
+    if (VEC == 4) hipLaunchKernelGGL(touched_dot_kernel<4>, grid, block, 0, stream, a, partials);
+    else hipLaunchKernelGGL(touched_dot_kernel<1>, grid, block, 0, stream, a, partials);
+    RS_CHECK_LAUNCH("rs_sparse_touched_dot");
+    return RS_OK;
+}
+
+// rs_clip_and_prepare with the tables' L2 term (see clip_prepare_l2_kernel): state = {G, S} in double precision,
+// scal = {norm, c} for the dense parameters, scal_tab = {norm, c / G'} for rs_sparse_update on the stored rows,
+// gscale = (float)G' for rs_gather_lr_fm_fwd_scaled; loss (optional) += lambda/2 * S before the step.
+int rs_clip_and_prepare_l2(const float* partials, int n_sparse, int n, const float* dot_partials, int n_dot,
+                           float max_norm, float emb_l2, double* state, float* scal, float* scal_tab, float* gscale,
+                           float* loss, long long* step, float* hyper, hipStream_t stream) {
+    RS_CHECK_ARG(partials && dot_partials && state && scal && scal_tab && gscale && step && hyper,
+                 "rs_clip_and_prepare_l2: null argument");
+    RS_CHECK_ARG(n_sparse >= 0 && n >= n_sparse && n_dot >= 0 && emb_l2 >= 0.f, "rs_clip_and_prepare_l2: bad sizes");
+    hipLaunchKernelGGL(clip_prepare_l2_kernel, dim3(1), dim3(1024), 0, stream, partials, n_sparse, n, dot_partials, n_dot,
+                       max_norm, emb_l2, state, scal, scal_tab, gscale, loss, step, hyper);
+    RS_CHECK_LAUNCH("rs_clip_and_prepare_l2");
+    return RS_OK;
+}
+
+// x[0, n) *= (float)*scale.
+int rs_scale_inplace(float* x, long long n, const double* scale, hipStream_t stream) {
+    RS_CHECK_ARG(n >= 0 && scale, "rs_scale_inplace: bad arguments");
+    if (n == 0) return RS_OK;
+    RS_CHECK_ARG(x, "rs_scale_inplace: null buffer");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((int)blocks), dim3(256), 0, stream, x, n, scale);
+    RS_CHECK_LAUNCH("rs_scale_inplace");
+    return RS_OK;
+}
 
 // *step += 1 and refresh the Adam bias-correction scalars in hyper[5], hyper[6].
 int rs_opt_prepare(long long* step, float* hyper, hipStream_t stream) {

@@ -18,8 +18,9 @@ Two embedding-update modes:
   zero-gradient steps of a row are replayed right before it is next read (rs_adam_catchup), so
   lookups, gradients and updates are those of the reference's dense optimizer; ``flush()`` brings
   every row up to date (evaluate / state_dict / a learning-rate change do it).  ``exact_adam=False``
-  is the "lazy" variant (absent rows keep their weights and moments).  Needs ``emb_regular`` to be
-  off (an L2 term on the tables gives every row a gradient).
+  is the "lazy" variant (absent rows keep their weights and moments).  ``emb_regular`` (an L2 term on
+  the tables gives every row a gradient) is carried for SGD on one GPU -- the rows off the batch only
+  shrink, by the same factor, which lives in one scalar (ops.TableShrink) -- and refused otherwise.
 * ``mode="dense"``: the reference's exact semantics -- row gradients are expanded into full-table
   gradients, L2 terms are added, and dense optimizer kernels sweep every table.  Used for
   bit-for-semantics parity tests and as the AUC reference for the sparse mode.
@@ -93,9 +94,14 @@ class FusedTrainer:
         self.lr = float(lr if lr is not None else model.learning_rate)
         self.emb_reg = model.emb_regular or 0.0
         self.net_reg = model.net_regular or 0.0
-        if mode == "sparse" and self.emb_reg:
-            raise RSError("FusedTrainer(mode='sparse'): emb_regular puts a gradient on every table row; "
-                          "use mode='dense' or turn emb_regular off")
+        # emb_regular puts the gradient lambda * w on EVERY table row.  Under SGD on one GPU that is a uniform shrink of
+        # the rows off the batch, which the touched-rows step carries in one scalar (ops.TableShrink); under Adam /
+        # Adagrad every row moves by its own amount in every step and only the dense sweep serves it.
+        self.shrink = None
+        self._shrink_mode = mode == "sparse" and bool(self.emb_reg)
+        if self._shrink_mode and (self.opt != "SGD" or type(self) is not FusedTrainer):
+            raise RSError("FusedTrainer(mode='sparse'): emb_regular puts a gradient on every table row; the touched-rows "
+                          "step carries it for SGD on one GPU only -- use mode='dense' or turn emb_regular off")
         self.dist = dist
         # dense Adam/AdamW semantics on the touched-rows path: replay a row's skipped zero-gradient steps before it is read
         self.exact = bool(exact_adam) and mode == "sparse" and self.opt in ("Adam", "AdamW")
@@ -134,7 +140,7 @@ class FusedTrainer:
             raise RSError("FusedTrainer: embedding tables are not on the device")
         # tables the reference owns but never looks up (they matter only under L2 regularisation)
         self.unused = []
-        if mode == "dense" and self.emb_reg:
+        if self.emb_reg:
             if self.has_emb:
                 self.unused.append(emb._tab1)
             else:
@@ -163,7 +169,7 @@ class FusedTrainer:
         self._graph_pool = None
         self._capture_error_mode = "global"
         # the base hooks run the whole step on this GPU; subclasses that put collectives between the pieces turn it off
-        self._fuse_small = type(self) is FusedTrainer
+        self._fuse_small = type(self) is FusedTrainer and not self._shrink_mode
         # LDS ring stages of the grouped dW + dX launch of a block's backward (0: one launch per product)
         self.group_gemms = ops.GROUP_STAGES
         self.last = {}
@@ -273,6 +279,11 @@ class FusedTrainer:
             t["tab"].row_state = None
         if self.exact:
             self._attach_row_state()
+        if self._shrink_mode:
+            # one scale for every table the reference regularises, looked up by the model or not
+            self.shrink = ops.TableShrink([t["w"] for t in self.tables], self.emb_reg, dev)
+            for t in self.tables:
+                t["tab"].row_state = self.shrink
 
     def _attach_row_state(self):
         """Per-row step counters of the looked-up tables; readers of the tables outside this engine (module forward,
@@ -294,6 +305,8 @@ class FusedTrainer:
         for t in self.tables:
             if t.get("rs") is not None:
                 t["rs"].flush()
+        if self.shrink is not None:
+            self.shrink.flush()
 
     def check(self):
         """Raise IndexError if a kernel saw an out-of-range index since the last check (the reference's nn.Embedding
@@ -462,7 +475,8 @@ class FusedTrainer:
         table1 = self.tab1.stacked if self.has_lr else None
         bias = self.lrm.bias.data if self.has_lr else None
         return ops.gather_lr_fm_fwd(idx, self.layout, table, table1, bias, want_emb=self.has_emb,
-                                    want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm)
+                                    want_sum=self.has_fm, want_lr=self.has_lr, want_fm=self.has_fm,
+                                    scale=self.shrink.gscale if self.shrink is not None else None)
 
     def _embed_forward_sorting(self, idx, plan, resume_passes: int = 0):
         """_embed_forward plus the index sort of the sparse backward (or its remaining passes) in the same launch."""
@@ -516,7 +530,8 @@ class FusedTrainer:
         if with_dense:
             plan.update_with_dense(self.opt, self.hyper, self.scal, self.flat_w, self.flat_g, self.flat_m, self.flat_v, **kw)
         else:
-            plan.update(self.opt, self.hyper, self.scal, **kw)
+            # (tables kept as w / G take the step with the coefficient c / G)
+            plan.update(self.opt, self.hyper, self.shrink.scal_tab if self.shrink is not None else self.scal, **kw)
 
     def _drops(self, b) -> bool:
         """Block b's output goes through dropout in this pass (Layers.py:33-37,46)."""
@@ -814,8 +829,16 @@ class FusedTrainer:
                 ops.sumsq_partials(t["g"], P[off:off + N_DENSE_PARTIALS])
                 off += N_DENSE_PARTIALS
             norm_in = P[n_sp:off]
-        ops.clip_and_prepare(norm_in, self.max_norm, self.scal, self.step_count, self.hyper)
-        if self.net_reg or self.emb_reg:
+        if self.shrink is not None:
+            # the tables' L2 term: 2 lambda <g, w> over the touched rows and lambda^2 ||W||^2 join the norm, the rows off
+            # the batch shrink through the scale, lambda/2 ||W||^2 joins the loss
+            te, t1 = self._table_entry(self.tab), self._table_entry(self.tab1)
+            dot = plan.touched_dot(table=te["w"] if te else None, table1=t1["w"].view(-1) if t1 else None)
+            self.shrink.clip_and_prepare(norm_in, n_sp, dot, self.max_norm, self.scal, self.step_count, self.hyper,
+                                         loss=loss)
+        else:
+            ops.clip_and_prepare(norm_in, self.max_norm, self.scal, self.step_count, self.hyper)
+        if self.net_reg or (self.emb_reg and self.mode == "dense"):
             loss = self._add_reg_to_loss(loss)
 
         # ---- optimizer --------------------------------------------------------------------------
@@ -850,6 +873,9 @@ class FusedTrainer:
         plan = self.last.get("plan")
         if plan is None:
             raise RSError("FusedTrainer.gradients: no step has run")
+        if self.shrink is not None:
+            raise RSError("FusedTrainer.gradients: with emb_regular on the touched-rows step the tables' gradients "
+                          "(lambda * w of the weights before the step) are never formed; use mode='dense' to look at them")
         coef = self.scal[1]
         out = {}
         dense = {id(p): n for n, p in self.model.named_parameters()}
@@ -915,6 +941,8 @@ class FusedTrainer:
         inside this step, beside its GEMMs and its update, and the next step starts with the lookup.  A promise that
         is not kept costs one small launch (the rows' stamps are taken back); results do not depend on next_idx."""
         self._check_tables()
+        if self.shrink is not None:
+            self.shrink.stepped()
         self._unchecked += 1
         if self.check_every and (self._unchecked >= self.check_every or self._first_poll):
             self._first_poll = False
@@ -1029,6 +1057,8 @@ class FusedTrainer:
                     ts.append(t[k])
             if t.get("rs") is not None:
                 ts += t["rs"].tensors()
+        if self.shrink is not None:
+            ts += self.shrink.tensors()
         for b in self.blocks:
             if b.normalization == "bn":
                 ts += [b.norm_layer.running_mean, b.norm_layer.running_var]

@@ -7,7 +7,7 @@ on torch's current stream.
 from __future__ import annotations
 
 import os
-from typing import Optional
+from typing import List, Optional
 
 import contextlib
 
@@ -131,8 +131,10 @@ def gather_fwd(idx: torch.Tensor, layout: FieldLayout, table: torch.Tensor) -> t
 
 def gather_lr_fm_fwd(idx: torch.Tensor, layout: FieldLayout, table: Optional[torch.Tensor],
                      table1: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-                     want_emb=True, want_sum=False, want_bi=False, want_lr=False, want_fm=False):
-    """Fused lookup; returns dict with the requested outputs (emb, sum, bi, lr, fm)."""
+                     want_emb=True, want_sum=False, want_bi=False, want_lr=False, want_fm=False,
+                     scale: Optional[torch.Tensor] = None):
+    """Fused lookup; returns dict with the requested outputs (emb, sum, bi, lr, fm).
+    scale: one float on the device every looked-up table value is multiplied by (TableShrink.gscale)."""
     Fn, B = idx.shape
     _chk(idx, torch.int64, "idx", (layout.num_fields, B))
     d = 1
@@ -156,6 +158,12 @@ def gather_lr_fm_fwd(idx: torch.Tensor, layout: FieldLayout, table: Optional[tor
         out["lr"] = torch.empty((B,), dtype=torch.float32, device=dev)
     if want_fm:
         out["fm"] = torch.empty((B,), dtype=torch.float32, device=dev)
+    if scale is not None:
+        _chk(scale, torch.float32, "scale", (1,))
+        call("rs_gather_lr_fm_fwd_scaled", ptr(idx), ptr(layout.row_offset_t), ptr(layout.vocab_t), ptr(table), ptr(table1),
+             ptr(bias), ptr(out.get("emb")), ptr(out.get("sum")), ptr(out.get("bi")), ptr(out.get("lr")),
+             ptr(out.get("fm")), B, Fn, d, ptr(scale), ptr(layout.err_flag), stream())
+        return out
     call("rs_gather_lr_fm_fwd", ptr(idx), ptr(layout.row_offset_t), ptr(layout.vocab_t), ptr(table), ptr(table1),
          ptr(bias), ptr(out.get("emb")), ptr(out.get("sum")), ptr(out.get("bi")), ptr(out.get("lr")),
          ptr(out.get("fm")), B, Fn, d, ptr(layout.err_flag), stream())
@@ -1034,6 +1042,15 @@ class SparsePlan:
         call("rs_sparse_scatter_dense", ptr(self.plan), self.F, self.cap, self.d, ptr(self.rowgrad),
              ptr(self.rowgrad1), ptr(grad), ptr(grad1), stream())
 
+    def touched_dot(self, table=None, table1=None) -> torch.Tensor:
+        """Partial sums of <reduced gradient, table row> over the distinct rows of the batch (both tables)."""
+        n = self.F * _lib.lib().rs_sparse_touched_dot_groups(self.cap, self.d)
+        if getattr(self, "_dot_partials", None) is None:
+            self._dot_partials = torch.zeros(n, dtype=torch.float32, device=self.plan.device)
+        call("rs_sparse_touched_dot", ptr(self.plan), self.F, self.cap, self.d, ptr(self.rowgrad), ptr(self.rowgrad1),
+             ptr(table), ptr(table1), ptr(self._dot_partials), n, stream())
+        return self._dot_partials
+
 
 def sumsq_partials(x: torch.Tensor, partials: torch.Tensor):
     _chk(x, torch.float32, "x")
@@ -1049,6 +1066,62 @@ def clip_and_prepare(partials: torch.Tensor, max_norm: float, scal: torch.Tensor
     """clip_coef + opt_prepare in one launch."""
     call("rs_clip_and_prepare", ptr(partials), partials.numel(), float(max_norm), ptr(scal), ptr(step), ptr(hyper),
          stream())
+
+
+class TableShrink:
+    """SGD with the reference's L2 term on embedding tables (model/utils/BaseModel.py:214-231: lambda/2 ||W||^2 of every
+    nn.Embedding) for a trainer that steps touched rows only.  Every row has the gradient g_r + lambda w_r, so rows off
+    the batch are multiplied by s = 1 - lr c lambda in every step (c: the clip coefficient).  The tables are kept as
+    w / G with ONE device scalar G for all of them: the shrink is G <- G s, a touched row's step is the plain SGD step
+    with c / G' in place of c, lookups multiply by G (gather_lr_fm_fwd(..., scale=gscale)), and the squared norm of
+    all rows, S, which the clipped norm needs, is carried along in closed form (rs_clip_and_prepare_l2).
+
+    Attached to every table holder as ``holder.row_state``: whoever reads a table outside the trainer (module forward,
+    evaluate, state_dict) calls flush(), which multiplies the stored rows by G and sets G = 1."""
+
+    FLUSH_EVERY = 4096       # steps between flushes, so that G stays far from the float32 underflow range
+
+    def __init__(self, weights: List[torch.Tensor], emb_l2: float, device):
+        self.weights = weights
+        self.emb_l2 = float(emb_l2)
+        s = 0.0
+        P = torch.zeros(256, dtype=torch.float32, device=device)
+        for w in weights:
+            sumsq_partials(w.view(-1), P)
+            s += float(P.double().sum().item())
+        self.state = torch.tensor([1.0, s], dtype=torch.float64, device=device)     # G, S
+        self.gscale = torch.ones(1, dtype=torch.float32, device=device)
+        self.scal_tab = torch.tensor([0.0, 1.0], dtype=torch.float32, device=device)
+        self.dirty = False
+        self.since_flush = 0
+
+    def tensors(self):
+        return [self.state, self.gscale, self.scal_tab]
+
+    def clip_and_prepare(self, partials, n_sparse, dot_partials, max_norm, scal, step, hyper, loss=None):
+        call("rs_clip_and_prepare_l2", ptr(partials), int(n_sparse), partials.numel(), ptr(dot_partials),
+             dot_partials.numel(), float(max_norm), self.emb_l2, ptr(self.state), ptr(scal), ptr(self.scal_tab),
+             ptr(self.gscale), ptr(loss), ptr(step), ptr(hyper), stream())
+
+    def stepped(self):
+        """Host bookkeeping of one step (captured or not): the tables are no longer the weights."""
+        self.dirty = True
+        self.since_flush += 1
+        if self.since_flush >= self.FLUSH_EVERY:
+            self.flush()
+
+    def flush(self):
+        if not self.dirty:
+            return
+        for w in self.weights:
+            call("rs_scale_inplace", ptr(w), w.numel(), ptr(self.state), stream())
+        self.state[0:1].fill_(1.0)
+        self.gscale.fill_(1.0)
+        self.dirty = False
+        self.since_flush = 0
+
+    def catch_up(self, idx, layout, mark_ahead=0):
+        self.flush()
 
 
 def dense_update(w, g, m, v, opt: str, hyper, scal):

@@ -124,26 +124,39 @@ def test_deepfm_benchmark_tower_dense_adam(graph):
               rtol=1e-4, atol_adam=2e-5)
 
 
-@pytest.mark.parametrize("opt", ["Adam", "AdamW"])
+@pytest.mark.parametrize("opt", ["Adam", "AdamW", "SGD+reg"])
 def test_benchmark_configuration_touched_rows_equals_dense_sweep(opt):
     """The benchmark's exact configuration -- 39 fields with the full vocabularies (2.71 M rows), embedding_dim 16, batch
     4096, tower 624-1024-512-256-1 -- for eight steps on non-repeating Zipf batches from one HIP graph per batch: the
     touched-rows step with replayed skips against the dense sweep over every row of every table (the reference's
     optimizer semantics, BaseModel.py:64-72,149), which needs no CPU oracle at this size.  Losses to 1e-5; weights to 2e-5
     with a floor of 1e-3 of one step (a rare row's first gradient can be as small as Adam's eps, where the step follows
-    the gradient's rounding noise)."""
+    the gradient's rounding noise).
+
+    "SGD+reg": SGD with regular = 1e-2 on tables of N(0, 0.05^2) rows (BaseModel.py:214-231: every one of the 2.71 M
+    rows of every table, the model's unused twin tables included, shrinks by 1 - lr c lambda per step and counts in the
+    clipped norm): the touched-rows step carries that in one scalar (ops.TableShrink) against the dense sweep."""
     from recommendsystem_amd import data, models
     from recommendsystem_amd.base_model import random_all
     vocab = data.criteo_x1_vocab_sizes()
     steps, lr = 8, 1e-3
+    kw = {}
+    if opt == "SGD+reg":
+        opt, lr, kw = "SGD", 0.05, {"regular": 1e-2}
     idxs, labs = data.synthetic_batches(vocab, 4096, steps, "cuda", seed=77)
     out = []
     for mode in ("dense", "sparse"):
         random_all(3)
         rec = data.criteo_x1_recorder(embedding_dim=16, batch_size=4096, vocab_sizes=vocab)
-        m = models.DeepFM(rec, lr, 0, hidden_dim_list=[1024, 512, 256], normalization=None, optimizer_type=opt)
+        m = models.DeepFM(rec, lr, 0, hidden_dim_list=[1024, 512, 256], normalization=None, optimizer_type=opt, **kw)
+        if kw:
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    if "embedded" in n:
+                        p[1:].normal_(0, 0.05)
         m.train()
         eng = m.use_fused_step(mode=mode, use_graph=(mode == "sparse"))
+        assert (eng.shrink is not None) == (bool(kw) and mode == "sparse")
         losses = [eng.step_tensors(idxs[s], labs[s], resident=True).clone() for s in range(steps)]
         eng.check()
         eng.flush()

@@ -20,6 +20,9 @@ FIXTURES = ["train_lr_adam_reg.npz", "train_fm_sgd.npz", "train_deepfm_adam.npz"
 # residual stacks (model/DeepCrossing/DeepCrossing.py:15-36): not part of the fused engine's model family
 RESIDUAL_FIXTURES = ["train_deepcrossing_sgd_bn.npz", "train_deepcrossing_adam_ln.npz"]
 LONG_FIXTURES = ["train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"]
+# SGD with emb_regular (BaseModel.py:214-231): every table row shrinks in every step; in the third trace lambda is
+# large enough for clip_grad_norm_ to bite, so the shrink factor changes from step to step
+REG_SGD_FIXTURES = ["train_lr_sgd_reg.npz", "train_deepfm_sgd_reg.npz", "train_fm_sgd_reg_clip.npz"]
 
 
 def build_model(g):
@@ -108,7 +111,7 @@ def compare_grads(have, g, s, fname, skip=lambda n: False, need_all=True):
     return seen
 
 
-@pytest.mark.parametrize("fname", FIXTURES + RESIDUAL_FIXTURES + LONG_FIXTURES)
+@pytest.mark.parametrize("fname", FIXTURES + RESIDUAL_FIXTURES + LONG_FIXTURES + REG_SGD_FIXTURES)
 def test_module_path_train_step(fname):
     g = load_golden(fname)
     m, feats = build_model(g)
@@ -138,7 +141,7 @@ def test_module_path_train_step(fname):
                       **(dict(rtol=2e-4, atol=2e-6) if fname == "train_deepcrossing_adam_ln.npz" else {}))
 
 
-@pytest.mark.parametrize("fname", FIXTURES)
+@pytest.mark.parametrize("fname", FIXTURES + REG_SGD_FIXTURES)
 @pytest.mark.parametrize("graph", [False, True])
 def test_fused_engine_dense_mode(fname, graph):
     g = load_golden(fname)
@@ -187,6 +190,42 @@ def test_fused_engine_sparse_mode_equals_dense_sgd(fname):
         torch.testing.assert_close(loss.cpu()[0], torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
         assert compare_grads(eng.gradients(), g, s, fname) > 0
         compare_state(m, g, f"step{s}.after.")
+
+
+@pytest.mark.parametrize("fname", REG_SGD_FIXTURES)
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("look_every_step", [True, False])
+def test_fused_engine_touched_rows_sgd_with_emb_regular(fname, graph, look_every_step):
+    """SGD + emb_regular on the touched-rows step against the reference's traces: the L2 term gives every row of every
+    nn.Embedding the gradient lambda * w (BaseModel.py:214-231), so rows off the batch shrink by 1 - lr c lambda per
+    step and all of them count in the clipped norm.  The engine keeps the tables as w / G with one scalar G
+    (ops.TableShrink) and never visits a row the batch does not touch; state_dict() turns the stored rows back into
+    weights.  look_every_step=False leaves the tables scaled for the whole trace and compares at its end."""
+    g = load_golden(fname)
+    m, feats = build_model(g)
+    eng = m.use_fused_step(mode="sparse", use_graph=graph)
+    assert eng.shrink is not None and not eng._fuse_small
+    steps = int(g["steps"])
+    for s in range(steps):
+        x = golden_batch(g, feats, f"step{s}.x.")
+        y = {"label": torch.from_numpy(g[f"step{s}.label"])}
+        idx = m.embedding_layer.index_matrix(m.features_to_divice(x))
+        torch.testing.assert_close(eng.logits(idx).cpu(), torch.from_numpy(g[f"step{s}.logits"]), rtol=1e-5, atol=1e-6)
+        loss = m.train_step(x, y)
+        torch.testing.assert_close(loss.cpu()[0], torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
+        if look_every_step or s == steps - 1:
+            compare_state(m, g, f"step{s}.after.")          # tables the model never looks up included
+    if not look_every_step:
+        assert abs(float(eng.shrink.state[0]) - 1.0) < 1e-12 and not eng.shrink.dirty      # state_dict() flushed
+    m.embedding_layer._tab.layout.check_indices()
+
+
+def test_touched_rows_emb_regular_needs_sgd_on_one_gpu():
+    from recommendsystem_amd._lib import RSError
+    g = load_golden("train_lr_adam_reg.npz")
+    m, _ = build_model(g)
+    with pytest.raises(RSError):
+        m.use_fused_step(mode="sparse")             # Adam: every row moves by its own amount in every step
 
 
 @pytest.mark.parametrize("fname", ["train_deepfm_adam.npz", "train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"])

@@ -115,7 +115,8 @@ def test_interactions():
 @pytest.mark.parametrize("fname", ["train_lr_adam_reg.npz", "train_fm_sgd.npz", "train_deepfm_adam.npz",
                                    "train_deepfm_sgd_bn.npz", "train_deepfm_adamw_reg.npz",
                                    "train_deepcrossing_sgd_bn.npz", "train_deepcrossing_adam_ln.npz",
-                                   "train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz"])
+                                   "train_deepfm_adam_long.npz", "train_deepfm_adamw_long.npz",
+                                   "train_lr_sgd_reg.npz", "train_deepfm_sgd_reg.npz", "train_fm_sgd_reg_clip.npz"])
 def test_train_steps(fname):
     g = load_golden(fname)
     fm, feats = golden_feature_map(g)
