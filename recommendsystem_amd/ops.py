@@ -1084,15 +1084,12 @@ class TableShrink:
     def __init__(self, weights: List[torch.Tensor], emb_l2: float, device):
         self.weights = weights
         self.emb_l2 = float(emb_l2)
-        s = 0.0
-        P = torch.zeros(256, dtype=torch.float32, device=device)
-        for w in weights:
-            sumsq_partials(w.view(-1), P)
-            s += float(P.double().sum().item())
-        self.state = torch.tensor([1.0, s], dtype=torch.float64, device=device)     # G, S
+        self.state = torch.tensor([1.0, 0.0], dtype=torch.float64, device=device)     # G, S
         self.gscale = torch.ones(1, dtype=torch.float32, device=device)
         self.scal_tab = torch.tensor([0.0, 1.0], dtype=torch.float32, device=device)
-        self.dirty = False
+        self._sq = torch.zeros(len(weights), 256, dtype=torch.float32, device=device)
+        self.dirty = False           # the tables hold w / G with G != 1
+        self.s_stale = True          # S must be taken from the tables again before the next step
         self.since_flush = 0
 
     def tensors(self):
@@ -1104,13 +1101,22 @@ class TableShrink:
              ptr(self.gscale), ptr(loss), ptr(step), ptr(hyper), stream())
 
     def stepped(self):
-        """Host bookkeeping of one step (captured or not): the tables are no longer the weights."""
-        self.dirty = True
-        self.since_flush += 1
+        """Host bookkeeping in front of a step (captured or not).  Whoever asked for a flush since the last step may
+        also have written the tables (load_state_dict): S is then summed over them again -- one pass over the tables,
+        no host synchronisation -- which also drops the rounding its closed-form updates have gathered."""
         if self.since_flush >= self.FLUSH_EVERY:
             self.flush()
+        if self.s_stale:
+            for i, w in enumerate(self.weights):
+                sumsq_partials(w.view(-1), self._sq[i])
+            self.state[1:2].copy_(self._sq.double().sum().view(1))
+            self.s_stale = False
+        self.dirty = True
+        self.since_flush += 1
 
     def flush(self):
+        """Stored rows -> weights (G = 1).  Called by everything that reads or writes the tables outside a step."""
+        self.s_stale = True
         if not self.dirty:
             return
         for w in self.weights:

@@ -220,6 +220,24 @@ def test_fused_engine_touched_rows_sgd_with_emb_regular(fname, graph, look_every
     m.embedding_layer._tab.layout.check_indices()
 
 
+def test_touched_rows_emb_regular_survives_load_state_dict():
+    """Weights written from outside between two steps (fit() ends with load_weights()): the scale goes back into the
+    rows first, and the squared norm of all rows that the clipped norm needs is taken from the new weights."""
+    g = load_golden("train_fm_sgd_reg_clip.npz")
+    m, feats = build_model(g)
+    init = {k: v.clone() for k, v in m.state_dict().items()}
+    eng = m.use_fused_step(mode="sparse", use_graph=True)
+    for s in range(2):
+        m.train_step(golden_batch(g, feats, f"step{s}.x."), {"label": torch.from_numpy(g[f"step{s}.label"])})
+    assert eng.shrink.dirty
+    m.load_state_dict(init)
+    for s in range(int(g["steps"])):
+        x = golden_batch(g, feats, f"step{s}.x.")
+        loss = m.train_step(x, {"label": torch.from_numpy(g[f"step{s}.label"])})
+        torch.testing.assert_close(loss.cpu()[0], torch.from_numpy(g[f"step{s}.loss"]), rtol=1e-5, atol=1e-7)
+    compare_state(m, g, f"step{int(g['steps']) - 1}.after.")
+
+
 def test_touched_rows_emb_regular_needs_sgd_on_one_gpu():
     from recommendsystem_amd._lib import RSError
     g = load_golden("train_lr_adam_reg.npz")
