@@ -270,6 +270,8 @@ def main():
     if args.launch_check and world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # collectives captured in HIP graphs: see recommendsystem_amd.dist.prepare_process_env
+        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
         launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
@@ -299,8 +301,7 @@ def main():
     model, rec, hidden = build(args, device)
     vocab = [rec.feature_map[c]["vocab_size"] for c in rec.features]
     kind = getattr(model, "KIND", None)
-    fused_kind = kind in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn") or (
-        kind == "pnn" and model.pnn_type == "inner" and not use_dist)
+    fused_kind = kind in ("lr", "fm", "deepfm", "dnn", "widedeep", "dcn") or (kind == "pnn" and model.pnn_type == "inner")
     if use_dist and fused_kind:
         from recommendsystem_amd.dist import DistributedTrainer, ReplicatedTablesTrainer
         cls = ReplicatedTablesTrainer if args.tables == "replicated" else DistributedTrainer

@@ -112,6 +112,17 @@ class BucketLayout:
 # -------------------------------------------------------------------------------------------------
 # collectives
 # -------------------------------------------------------------------------------------------------
+def prepare_process_env():
+    """Environment a process should have BEFORE it creates its process groups when collectives are going to be captured
+    in HIP graphs (DistributedTrainer(use_graph=True)): torch's NCCL process groups then take a fresh event for every
+    collective instead of one from their per-device pool.  The watchdog thread of a process group aborts the process
+    when it queries an event "last recorded in a capturing stream" (hipErrorCapturedEvent); that abort was seen once in
+    several hundred captures, with several trainers built one after the other in one process, and an event that a
+    captured collective recorded and returned to the pool is the suspected way for the watchdog to meet one."""
+    import os
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+
+
 class Comm:
     """torch.distributed wrapper.  stage_cpu=True moves tensors through host memory around each
     collective (for the gloo backend, which is what the CPU tests and single-GPU rehearsals use).
@@ -509,8 +520,6 @@ class DistributedTrainer(FusedTrainer):
                  bucket_slack: float = 1.5, overlap_comm: Optional[bool] = None, **kw):
         if mode != "sparse":
             raise RSError("DistributedTrainer: row-sharded tables use the touched-rows (sparse) update")
-        if getattr(model, "KIND", None) in ("dcn", "pnn"):
-            raise RSError("DistributedTrainer: DCN and PNN run on several GPUs through DistributedSparseTrainer")
         if use_graph and stage_cpu:
             raise RSError("DistributedTrainer: collectives staged through host memory (gloo) cannot be captured in a HIP graph")
         self.comm = Comm(group, stage_cpu=stage_cpu)

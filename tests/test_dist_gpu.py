@@ -60,12 +60,15 @@ def compare_weights(got, m, kind, optimizer):
                                                   ("lr", "AdamW", ""), ("dnn", "Adam", ""),
                                                   ("deepfm", "Adam", "onestream"), ("fm", "SGD", "onestream"),
                                                   ("deepfm_bn", "SGD", ""), ("deepfm_bn", "Adam", ""),
-                                                  ("dnn_bn", "SGD", "onestream")])
+                                                  ("dnn_bn", "SGD", "onestream"),
+                                                  ("dcn", "Adam", ""), ("dcn_bn", "SGD", "onestream"),
+                                                  ("pnn", "Adam", ""), ("pnn_bn", "SGD", "")])
 def test_two_ranks_match_single_gpu_union_batch(kind, optimizer, extra, tmp_path):
     """Default: the dense all-reduce on a second stream and communicator beside the gradient exchange; onestream:
     everything on one stream (the dense gradient's norm partials then ride in the owner's reduction).  *_bn: towers with
     BatchNorm in every block (the reference's default): batch statistics over the union of the ranks' batches, running
-    statistics included in the comparison."""
+    statistics included in the comparison.  dcn / pnn: the hand-scheduled DCN and PNN-inner steps (cross network
+    parameters and the padded first-layer weight ride in the flat buffer's all-reduce)."""
     world = 2
     codes, outs = run_ranks(world, ["gpu", str(tmp_path), kind, optimizer] + ([extra] if extra else []), timeout=200)
     assert codes == [0] * world, "\n".join(outs)
@@ -107,7 +110,7 @@ def test_two_ranks_replicated_tables_match_single_gpu_union_batch(kind, optimize
 
 
 @pytest.mark.parametrize("kind,optimizer", [("deepfm", "Adam"), ("deepfm", "SGD"), ("fm", "AdamW"), ("lr", "Adagrad"),
-                                            ("dnn", "Adam"), ("deepfm_bn", "SGD")])
+                                            ("dnn", "Adam"), ("deepfm_bn", "SGD"), ("dcn", "Adam"), ("pnn", "SGD")])
 def test_one_rank_rccl_graph_matches_eager(kind, optimizer, tmp_path):
     """The real RCCL calls on a one-rank group: the step issued eagerly, the whole step as ONE HIP graph with the
     collectives captured inside, that graph with the dense all-reduce on the second stream and communicator, and (eagerly
