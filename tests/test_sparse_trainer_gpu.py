@@ -123,6 +123,7 @@ def test_ffm_step_at_criteo_shape(optimizer, use_graph):
     assert eng.step_count.item() == steps
 
 
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("optimizer,kw", [
     ("SGD", dict(hidden_dim_list=[32, 16], cross_layers_num=3, normalization=None)),
@@ -131,13 +132,13 @@ def test_ffm_step_at_criteo_shape(optimizer, use_graph):
     ("SGD", dict(hidden_dim_list=[32, 16], cross_layers_num=2, normalization="bn")),
     ("Adam", dict(hidden_dim_list=[32], cross_layers_num=1, normalization="ln")),
 ], ids=["sgd", "adam", "adamw-tanh", "sgd-bn", "adam-ln"])
-def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
+def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph, mode):
     """DCN (model/DCN/DCN.py:48-52) on the hand-scheduled step (engine.FusedTrainer: cross network forward / backward,
     the two-block 1-wide head with the tower's last act' fused, everything else as for DeepFM) against the CPU oracle's
     dense torch step, as the generic trainer is checked above."""
     m, rec = build("dcn", "SGD", **kw)
     o = make_oracle("dcn", m, rec, kw)
-    eng = m.use_fused_step(mode="sparse", optimizer_type=optimizer, lr=1e-2, use_graph=graph)
+    eng = m.use_fused_step(mode=mode, optimizer_type=optimizer, lr=1e-2, use_graph=graph)
     opt = O.make_optimizer(optimizer, o.parameters(), 1e-2)
     g = torch.Generator().manual_seed(123)
     steps = 3
@@ -159,6 +160,7 @@ def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
     assert eng.step_count.item() == steps
 
 
+@pytest.mark.parametrize("mode", ["sparse", "dense"])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("optimizer,kw", [
     ("SGD", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization=None)),
@@ -167,13 +169,13 @@ def test_dcn_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
     ("SGD", dict(hidden_dim_list=[32, 16], pnn_type="inner", normalization="bn")),
     ("Adam", dict(hidden_dim_list=[32], pnn_type="inner", normalization="ln")),
 ], ids=["sgd", "adam", "adamw-tanh", "sgd-bn", "adam-ln"])
-def test_pnn_inner_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph):
+def test_pnn_inner_on_the_fused_engine_matches_dense_oracle(optimizer, kw, graph, mode):
     """PNN with inner products (model/PNN/PNN.py:58,80-89) on the hand-scheduled step (engine.FusedTrainer): the tower
     reads [embeddings | inner products] rows of 63 floats here, kept padded to 64 in the flat weight buffer, so the
     first layer's weight is a strided view of its padded block.  Checked against the CPU oracle's dense torch step."""
     m, rec = build("pnn", "SGD", **kw)
     o = make_oracle("pnn", m, rec, kw)
-    eng = m.use_fused_step(mode="sparse", optimizer_type=optimizer, lr=1e-2, use_graph=graph)
+    eng = m.use_fused_step(mode=mode, optimizer_type=optimizer, lr=1e-2, use_graph=graph)
     w0 = m.mlp[0].fc.weight
     assert w0.shape[1] == 63 and w0.stride(0) == 64
     opt = O.make_optimizer(optimizer, o.parameters(), 1e-2)
