@@ -45,16 +45,29 @@ __device__ __forceinline__ float pow_int(float b, int n) {
     return powf(b, (float)n);
 }
 
-// (w, m, v) after the zero-gradient optimizer steps s+1 .. s+n.
-template <int VEC>
+// b of any of the four lanes 4q .. 4q+3 this lane belongs to (all four must be executing)
+__device__ __forceinline__ bool quad_any(bool b) {
+    int x = b ? 1 : 0;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);     // quad_perm [2,3,0,1]
+    return x != 0;
+}
+
+// (w, m, v) after the zero-gradient optimizer steps s+1 .. s+n.  The loop runs while any of the lane's VEC elements
+// still moves its weight.  QUAD (VEC = 1): four neighbouring lanes hold the four elements that one lane of the VEC = 4
+// form holds and leave the loop together, so both forms execute the same arithmetic on every element -- the same bits --
+// and a caller may pick either one by how many lanes it has to spare.
+template <int VEC, bool QUAD = false>
 __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, float (&w)[VEC], float (&m)[VEC],
                                                        float (&v)[VEC], int s, int n) {
+    static_assert(!QUAD || VEC == 1, "the quad form holds one element per lane");
     const bool adamw = c.opt == RS_OPT_ADAMW;
     const float omb1 = 1.f - c.b1;
     const float decay = 1.f - c.lr * c.wd;
     bool moving = false;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) moving |= (m[e] != 0.f);
+    if constexpr (QUAD) moving = quad_any(moving);
     int done = 0;
     if (moving) {
         float sq[VEC];
@@ -62,11 +75,10 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
         for (int e = 0; e < VEC; ++e) sq[e] = sqrtf(v[e]);
         const float rb2 = sqrtf(c.b2);
         const int nloop = n < c.kmax ? n : c.kmax;
-        float2 bc_next = bias_corrections(c, s + 1);
-        while (done < nloop) {
-            ++done;
-            const float2 bc = bc_next;
-            bc_next = bias_corrections(c, s + done + 1);       // in flight while this step's arithmetic runs
+        const int klast = s + nloop;
+        // one zero-gradient step with its scalars bc = {1/(1 - beta1^k), 1/sqrt(1 - beta2^k)}; false once no element
+        // of this lane moves its weight any more
+        auto one_step = [&](const float2 bc) -> bool {
             const float ss = c.lr * bc.x;
             bool live = false;
 #pragma unroll
@@ -79,7 +91,46 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
                 w[e] -= term;
                 live |= fabsf(term) > 7.5e-9f * fabsf(w[e]);
             }
-            if (!live) break;
+            return live;
+        };
+        if (klast < c.tab_n) {
+            // The scalars come from the table, one entry per step.  One step's arithmetic is far shorter than the latency
+            // of that load and a long replay is one dependent chain, so the steps go in groups of four with four
+            // entries in flight, each in a register pair of its own, and no branch inside a group (a load under a
+            // condition, or a rotating queue, makes every step wait for the newest load).  Whether the weights still
+            // move is looked at once per group: up to three more (real) steps than needed are replayed.
+            float2 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = c.bctab[min(s + 1 + j, klast)];
+            bool live = true;
+            while (done + 4 <= nloop) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 bc = q[j];
+                    q[j] = c.bctab[min(s + done + 5 + j, klast)];
+                    live = one_step(bc);
+                }
+                done += 4;
+                if constexpr (QUAD) live = quad_any(live);
+                if (!live) break;
+            }
+            if (live) {                                    // fewer than four steps are left: q[j] holds step done+1+j
+                const int r = nloop - done;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j < r) one_step(q[j]);
+                done = nloop;
+            }
+        } else {
+            float2 bc_next = bias_corrections(c, s + 1);
+            while (done < nloop) {
+                ++done;
+                const float2 bc = bc_next;
+                bc_next = bias_corrections(c, s + done + 1);
+                bool live = one_step(bc);
+                if constexpr (QUAD) live = quad_any(live);
+                if (!live) break;
+            }
         }
     }
     const int rest = n - done;
@@ -110,14 +161,14 @@ __device__ __forceinline__ void row_st(float* p, const float (&x)[VEC]) {
     else *p = x[0];
 }
 
-template <int VEC>
+template <int VEC, bool QUAD = false>
 __device__ __forceinline__ void replay_row_slice(const ReplayConsts& c, const RowTab& t, long long row, int co, int s, int n) {
     const long long o = row * t.d + co;
     float w[VEC], m[VEC], v[VEC];
     row_ld<VEC>(t.w + o, w);
     row_ld<VEC>(t.m + o, m);
     row_ld<VEC>(t.v + o, v);
-    replay_zero_grad_steps<VEC>(c, w, m, v, s, n);
+    replay_zero_grad_steps<VEC, QUAD>(c, w, m, v, s, n);
     row_st<VEC>(t.w + o, w);
     row_st<VEC>(t.m + o, m);
     row_st<VEC>(t.v + o, v);
@@ -140,10 +191,16 @@ struct CatchArgs {
 // owner (whichever it is, the result is the same).  Rows that are up to date -- the hot rows of a Zipf batch, stepped
 // and stamped by the previous step's update -- cost one load and no atomic.
 // Phase 2: the workgroup replays the rows its threads own, d/VEC lanes per row.
-// NT threads per workgroup; `block` = index of the workgroup among those that do this work; s_row, s_last: NT ints each.
+// Rows of up to FINE_MAX_D floats (a multiple of four) whose first moment is not zero -- the ones whose replay is a loop
+// of up to kmax steps -- are moved to the front of the list first; when they are few enough to leave lanes idle, a lane
+// per element replays them (the quad form above) instead of a lane per four elements: a quarter of the time per step.
+// NT threads per workgroup; `block` = index of the workgroup among those that do this work; s_row, s_last, s_row2,
+// s_last2: NT ints each; s_n: 3 ints.
+constexpr int FINE_MAX_D = 64;
 template <int VEC, int NT>
-__device__ __forceinline__ void catchup_body(const CatchArgs& a, const RowTab& t, int block, int* s_n, int* s_row, int* s_last) {
-    if (threadIdx.x == 0) *s_n = 0;
+__device__ __forceinline__ void catchup_body(const CatchArgs& a, const RowTab& t, int block, int* s_n, int* s_row, int* s_last,
+                                             int* s_row2, int* s_last2) {
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
     __syncthreads();
     const long long e = (long long)block * NT + threadIdx.x;
     const int c = (int)*a.step;
@@ -178,18 +235,47 @@ __device__ __forceinline__ void catchup_body(const CatchArgs& a, const RowTab& t
     if (items == 0) return;
     const int C = t.d / VEC, gpb = NT / C;
     const int grp = threadIdx.x / C, cc = threadIdx.x - grp * C;
-    if (grp >= gpb) return;
     const ReplayConsts k = load_consts(a.hyper, a.opt, a.bctab, a.tab_n, a.kmax);
+    if constexpr (VEC == 4) {
+        if (t.d <= FINE_MAX_D && NT % t.d == 0) {                          // uniform over the workgroup
+            // the rows with a loop to run in front (s_row2[0, nh)), the others from the back
+            if ((int)threadIdx.x < items) {
+                const int row = s_row[threadIdx.x];
+                bool mv = false;
+                for (int q = 0; q < C; ++q) {
+                    const float4 mm = *reinterpret_cast<const float4*>(t.m + (long long)row * t.d + 4 * q);
+                    mv |= (mm.x != 0.f) | (mm.y != 0.f) | (mm.z != 0.f) | (mm.w != 0.f);
+                }
+                const int p = mv ? atomicAdd(s_n + 1, 1) : NT - 1 - atomicAdd(s_n + 2, 1);
+                s_row2[p] = row; s_last2[p] = s_last[threadIdx.x];
+            }
+            __syncthreads();
+            const int nh = s_n[1], nl = s_n[2];
+            const int gpb1 = NT / t.d;
+            if (nh <= 3 * gpb1) {
+                const int grp1 = threadIdx.x / t.d, cc1 = threadIdx.x - grp1 * t.d;
+                for (int i = grp1; i < nh; i += gpb1)
+                    replay_row_slice<1, true>(k, t, s_row2[i], cc1, s_last2[i], c - s_last2[i]);
+            } else if (grp < gpb) {
+                for (int i = grp; i < nh; i += gpb) replay_row_slice<4>(k, t, s_row2[i], cc * 4, s_last2[i], c - s_last2[i]);
+            }
+            if (grp < gpb)
+                for (int i = grp; i < nl; i += gpb)
+                    replay_row_slice<4>(k, t, s_row2[NT - 1 - i], cc * 4, s_last2[NT - 1 - i], c - s_last2[NT - 1 - i]);
+            return;
+        }
+    }
+    if (grp >= gpb) return;
     for (int i = grp; i < items; i += gpb) replay_row_slice<VEC>(k, t, s_row[i], cc * VEC, s_last[i], c - s_last[i]);
 }
 
 // workgroup `block` of the nt * ceil(B*F / NT) that serve a batch: table block / per_table, entries of block % per_table
 template <int NT>
 __device__ __forceinline__ void catchup_block(const CatchArgs& a, int block, int per_table) {
-    __shared__ int s_n, s_row[NT], s_last[NT];
+    __shared__ int s_n[3], s_row[NT], s_last[NT], s_row2[NT], s_last2[NT];
     const RowTab t = a.t[block / per_table];
-    if (t.d % 4 == 0) catchup_body<4, NT>(a, t, block % per_table, &s_n, s_row, s_last);
-    else catchup_body<1, NT>(a, t, block % per_table, &s_n, s_row, s_last);
+    if (t.d % 4 == 0) catchup_body<4, NT>(a, t, block % per_table, s_n, s_row, s_last, s_row2, s_last2);
+    else catchup_body<1, NT>(a, t, block % per_table, s_n, s_row, s_last, s_row2, s_last2);
 }
 
 // ---- the same replay for the DISTINCT rows of a sorted batch (the plan of the sparse backward) -------------------
