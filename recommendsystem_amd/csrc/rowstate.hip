@@ -15,8 +15,9 @@
 //                     as torch computes them on the host
 //
 // The replay is exact up to rounding: the drift terms decay like (beta1/sqrt(beta2))^j, so the loop stops once a
-// term is below 2^-27 of the weight (the remaining tail is < 10 terms of that size) or after kmax steps; what is
-// left of the skipped steps only decays m, v (and, for AdamW, w) and is applied in closed form.
+// term is below 2^-27 of the weight (the remaining tail is < 10 terms of that size; looked at every eighth step) or
+// after kmax steps; what is left of the skipped steps only decays m, v (and, for AdamW, w) and is applied in closed
+// form.
 #include "rowstate_body.h"
 #include "plan.h"
 

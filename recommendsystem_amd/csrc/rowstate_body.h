@@ -95,29 +95,30 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
         };
         if (klast < c.tab_n) {
             // The scalars come from the table, one entry per step.  One step's arithmetic is far shorter than the latency
-            // of that load and a long replay is one dependent chain, so the steps go in groups of four with four
-            // entries in flight, each in a register pair of its own, and no branch inside a group (a load under a
-            // condition, or a rotating queue, makes every step wait for the newest load).  Whether the weights still
-            // move is looked at once per group: up to three more (real) steps than needed are replayed.
-            float2 q[4];
+            // of that load and a long replay is one dependent chain, so the steps go in groups of NQ with NQ entries in
+            // flight, each in a register pair of its own that is refilled right after its step has used it, and no
+            // branch inside a group (a load under a condition, or a rotating queue, makes every step wait for the
+            // newest load).  Whether the weights still move is looked at once per group: up to NQ - 1 more (real) steps
+            // than needed are replayed.
+            constexpr int NQ = 8;
+            float2 q[NQ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] = c.bctab[min(s + 1 + j, klast)];
+            for (int j = 0; j < NQ; ++j) q[j] = c.bctab[min(s + 1 + j, klast)];
             bool live = true;
-            while (done + 4 <= nloop) {
+            while (done + NQ <= nloop) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float2 bc = q[j];
-                    q[j] = c.bctab[min(s + done + 5 + j, klast)];
-                    live = one_step(bc);
+                for (int j = 0; j < NQ; ++j) {
+                    live = one_step(q[j]);
+                    q[j] = c.bctab[min(s + done + 1 + NQ + j, klast)];
                 }
-                done += 4;
+                done += NQ;
                 if constexpr (QUAD) live = quad_any(live);
                 if (!live) break;
             }
-            if (live) {                                    // fewer than four steps are left: q[j] holds step done+1+j
+            if (live) {                                    // fewer than NQ steps are left: q[j] holds step done+1+j
                 const int r = nloop - done;
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < NQ - 1; ++j)
                     if (j < r) one_step(q[j]);
                 done = nloop;
             }

@@ -35,6 +35,7 @@ run() { echo "== bench.py $*" >&2; timeout -k 10 400 python bench.py "$@" >> "$V
 run --exact-adam 0 --cpu-baseline 0                      # lazy Adam: what the exact replay costs
 run --mode dense --cpu-baseline 0 --steps 20             # the reference's dense optimizer sweep
 run --distinct-batches 64 --steps 128 --warmup 64 --cpu-baseline 0 --event-pass 0    # rows come back after 64 steps
+run --steps 300 --warmup 10 --cpu-baseline 0 --event-pass 0    # a longer run: returning rows have more skipped steps to replay
 run --uniform 1 --cpu-baseline 0
 run --fields 26 --cpu-baseline 0
 run --cpu-threads 1 --cpu-seconds 15 --event-pass 0
@@ -43,6 +44,12 @@ for m in ffm pnn_inner dcn nfm afm; do
   run --model $m --steps 20 --warmup 5 --cpu-baseline 0
 done
 run --model pnn_inner --activation tanh --steps 20 --warmup 5 --cpu-baseline 0       # a 1-wide head that is not a dead ReLU
+# FFM's replay of skipped Adam steps works on rows of 2.5 KB: how the step depends on how stale the rows are
+run --model ffm --steps 100 --warmup 5 --cpu-baseline 0 --event-pass 0
+run --model ffm --distinct-batches 64 --steps 128 --warmup 64 --cpu-baseline 0 --event-pass 0
+run --model ffm --steps 20 --warmup 5 --exact-adam 0 --cpu-baseline 0 --event-pass 0
+run --optimizer SGD --regular 1e-4 --cpu-baseline 0 --event-pass 0                    # SGD + emb_regular on touched rows
+run --optimizer SGD --regular 1e-4 --mode dense --steps 20 --cpu-baseline 0 --event-pass 0
 for m in dcn pnn_inner; do
   run --model $m --batch 16384 --steps 10 --warmup 3 --cpu-baseline 0
 done
