@@ -565,6 +565,9 @@ def main():
                              else "sparse, lazy: absent rows keep weights and moments"),
                        "index_distribution": "uniform" if args.uniform else "zipf(1.1)",
                        "distinct_batches": nb, "next_batch_announced": bool(use_next),
+                       # exact Adam replays a returning row's skipped steps, so the step costs more once rows have been
+                       # away for long (it levels off after some hundred steps): how old the tables are when timing starts
+                       "steps_before_timed_region": args.warmup,
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": ("single GPU" if not use_dist else
                                        "one rank of the N>1 step (--force-dist): "
