@@ -18,6 +18,7 @@ struct ReplayConsts {
     float lr, b1, b2, eps, wd;
     int opt, kmax, tab_n;
     const float2* bctab;
+    bool tail_one;      // the table's last entry is {1, 1} in float: so is every later step's (both corrections fall to 1)
 };
 
 __device__ __forceinline__ ReplayConsts load_consts(const float* __restrict__ hyper, int opt, const float* bctab, int tab_n,
@@ -26,12 +27,18 @@ __device__ __forceinline__ ReplayConsts load_consts(const float* __restrict__ hy
     c.lr = hyper[0]; c.b1 = hyper[1]; c.b2 = hyper[2]; c.eps = hyper[3]; c.wd = hyper[4];
     c.opt = opt; c.kmax = kmax; c.tab_n = tab_n;
     c.bctab = reinterpret_cast<const float2*>(bctab);
+    c.tail_one = false;
+    if (tab_n > 1) {
+        const float2 t = c.bctab[tab_n - 1];
+        c.tail_one = t.x == 1.f && t.y == 1.f;
+    }
     return c;
 }
 
 // {1/(1 - beta1^k), 1/sqrt(1 - beta2^k)}
 __device__ __forceinline__ float2 bias_corrections(const ReplayConsts& c, int k) {
     if (k < c.tab_n) return c.bctab[k];
+    if (c.tail_one) return make_float2(1.f, 1.f);
     const double b1 = (double)c.b1, b2 = (double)c.b2;
     return make_float2((float)(1.0 / (1.0 - pow(b1, (double)k))), (float)(1.0 / sqrt(1.0 - pow(b2, (double)k))));
 }
@@ -93,7 +100,7 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
             }
             return live;
         };
-        if (klast < c.tab_n) {
+        if (klast < c.tab_n || c.tail_one) {
             // The scalars come from the table, one entry per step.  One step's arithmetic is far shorter than the latency
             // of that load and a long replay is one dependent chain, so the steps go in groups of NQ with NQ entries in
             // flight, each in a register pair of its own that is refilled right after its step has used it, and no
@@ -102,14 +109,15 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
             // than needed are replayed.
             constexpr int NQ = 8;
             float2 q[NQ];
+            const int kcap = min(klast, c.tab_n - 1);      // (steps past the table: its last entry, {1, 1})
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) q[j] = c.bctab[min(s + 1 + j, klast)];
+            for (int j = 0; j < NQ; ++j) q[j] = c.bctab[min(s + 1 + j, kcap)];
             bool live = true;
             while (done + NQ <= nloop) {
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
                     live = one_step(q[j]);
-                    q[j] = c.bctab[min(s + done + 1 + NQ + j, klast)];
+                    q[j] = c.bctab[min(s + done + 1 + NQ + j, kcap)];
                 }
                 done += NQ;
                 if constexpr (QUAD) live = quad_any(live);

@@ -361,8 +361,9 @@ def test_out_of_range_index_is_reported_by_the_periodic_poll():
             m.train_step(good, y)
 
 
-def _deepfm_pair_states(betas, opt, steps=14):
-    """The same model stepped by the dense sweep and by the touched-rows step with replayed skips; (dense, exact)."""
+def _deepfm_pair_states(betas, opt, steps=14, start_step=0):
+    """The same model stepped by the dense sweep and by the touched-rows step with replayed skips; (dense, exact).
+    start_step: the optimizers' step counters start there (every row up to date at that step)."""
     from recommendsystem_amd import data, models
     from recommendsystem_amd.base_model import random_all
     vocab = [7, 40, 300, 2500, 20000, 3]
@@ -373,6 +374,11 @@ def _deepfm_pair_states(betas, opt, steps=14):
         m = models.DeepFM(rec, 1e-2, 0, hidden_dim_list=[32, 16], normalization=None, optimizer_type=opt)
         m.train()
         eng = m.use_fused_step(mode=mode, betas=betas)
+        if start_step:
+            eng.step_count.fill_(start_step)
+            for t in eng.tables:
+                if t.get("rs") is not None:
+                    t["rs"].last.fill_(start_step)
         idxs, labs = data.synthetic_batches(vocab, 64, steps, "cuda", seed=9)
         order = [0, 1, 2, 0, 3, 4, 5, 1, 6, 7, 8, 2, 9, 0]
         for s in range(steps):
@@ -396,6 +402,22 @@ def test_exact_adam_other_betas_equals_dense_sweep(betas, opt):
     # noise of everything upstream (the two runs differ by rounding in other rows from the first replay on).
     for k in dense:
         torch.testing.assert_close(exact[k], dense[k], rtol=2e-5, atol=1e-5, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("betas", [(0.9, 0.999), (0.9, 0.9999)])
+def test_exact_adam_past_the_end_of_the_bias_correction_table(betas):
+    """The replay reads 1/(1 - beta1^k) and 1/sqrt(1 - beta2^k) from a table of 65536 steps.  Past its end both are
+    exactly 1 in float for torch's default betas (the replay then keeps reading the last entry); with beta2 = 0.9999 they
+    are not yet, and the replay computes them in double precision as the table's builder does.  Fourteen steps across
+    step 65536 against the dense sweep."""
+    dense, exact = _deepfm_pair_states(betas, "Adam", start_step=65530)
+    # atol = 1e-3 of one step, as above.  Without a bias correction to speak of (1 - beta2^65530 is 0.9986 resp. 1) a first
+    # step is lr * (1 - beta1) g / (sqrt(1 - beta2) |g| + eps): 0.032 for beta2 = 0.999 as long as |g| >> 3e-7, and 0.1
+    # for beta2 = 0.9999 as long as |g| >> 1e-6 -- ten times the step and three times the range of gradients in which
+    # the step follows g's rounding noise
+    atol = 1e-5 if betas[1] < 0.9995 else 1e-4
+    for k in dense:
+        torch.testing.assert_close(exact[k], dense[k], rtol=2e-5, atol=atol, msg=lambda s, k=k: f"{k}: {s}")
 
 
 def test_exact_adam_refuses_betas_whose_drift_does_not_decay():
