@@ -42,6 +42,10 @@ def parse():
                    help="39 = 13 small-vocabulary + 26 categorical fields; 26 = the categorical fields only")
     p.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores))")
     p.add_argument("--optimizer", type=str, default="Adam")
+    p.add_argument("--age-steps", type=int, default=0,
+                   help="untimed training steps on further non-repeating batches before the warm-up (single GPU): exact "
+                        "Adam replays a returning row's skipped steps, so the step costs more once the tables have a "
+                        "history; some thousand steps reach the level a long run settles at")
     p.add_argument("--regular", type=float, default=0.0,
                    help="emb_regular = net_regular (BaseModel.py:214-231); with --optimizer SGD the touched-rows step "
                         "carries the tables' shrink in one scalar, other optimizers need --mode dense; not part of "
@@ -361,6 +365,15 @@ def main():
             for i in range(args.warmup + args.steps):
                 kw = dict(announce(i), ahead_slot=(i % 2) if i > 0 else None) if use_next else {}
                 eng.prepare(idx_dev[i % nb], lab_dev[i % nb], **kw)
+    aged = 0
+    if args.age_steps > 0 and not use_dist:
+        while aged < args.age_steps:
+            n = min(64, args.age_steps - aged)
+            bi, bl = data.synthetic_batches(vocab, args.batch, n, device, seed=77_000 + aged, uniform=bool(args.uniform))
+            for i in range(n):
+                eng.step_tensors(bi[i], bl[i])       # (with --graph: one graph over static buffers the batch is copied into)
+            aged += n
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         run_step(i)
     torch.cuda.synchronize()
@@ -567,7 +580,7 @@ def main():
                        "distinct_batches": nb, "next_batch_announced": bool(use_next),
                        # exact Adam replays a returning row's skipped steps, so the step costs more once rows have been
                        # away for long (it levels off after some hundred steps): how old the tables are when timing starts
-                       "steps_before_timed_region": args.warmup,
+                       "steps_before_timed_region": args.warmup + aged,
                        "total_table_rows": sum(vocab), "hip_graph": bool(eng.use_graph),
                        "parallelism": ("single GPU" if not use_dist else
                                        "one rank of the N>1 step (--force-dist): "

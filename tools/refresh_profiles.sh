@@ -36,6 +36,7 @@ run --exact-adam 0 --cpu-baseline 0                      # lazy Adam: what the e
 run --mode dense --cpu-baseline 0 --steps 20             # the reference's dense optimizer sweep
 run --distinct-batches 64 --steps 128 --warmup 64 --cpu-baseline 0 --event-pass 0    # rows come back after 64 steps
 run --steps 300 --warmup 10 --cpu-baseline 0 --event-pass 0    # a longer run: returning rows have more skipped steps to replay
+run --age-steps 3000 --cpu-baseline 0 --event-pass 0           # the level a long run settles at: tables with 3000 steps of history
 run --uniform 1 --cpu-baseline 0
 run --fields 26 --cpu-baseline 0
 run --cpu-threads 1 --cpu-seconds 15 --event-pass 0
@@ -48,6 +49,7 @@ run --model pnn_inner --activation tanh --steps 20 --warmup 5 --cpu-baseline 0  
 run --model ffm --steps 100 --warmup 5 --cpu-baseline 0 --event-pass 0
 run --model ffm --distinct-batches 64 --steps 128 --warmup 64 --cpu-baseline 0 --event-pass 0
 run --model ffm --steps 20 --warmup 5 --exact-adam 0 --cpu-baseline 0 --event-pass 0
+run --model ffm --steps 20 --warmup 5 --age-steps 1000 --cpu-baseline 0 --event-pass 0
 run --optimizer SGD --regular 1e-4 --cpu-baseline 0 --event-pass 0                    # SGD + emb_regular on touched rows
 run --optimizer SGD --regular 1e-4 --mode dense --steps 20 --cpu-baseline 0 --event-pass 0
 for m in dcn pnn_inner; do
