@@ -15,7 +15,8 @@
 //                     as torch computes them on the host
 //
 // The replay is exact up to rounding: the drift terms decay like (beta1/sqrt(beta2))^j, so the loop stops once a
-// term is below 2^-27 of the weight (the remaining tail is < 10 terms of that size; looked at every eighth step) or
+// term is below 2^-25 of the weight (under half an ulp: neither it nor any later, smaller term changes the weight in
+// the dense optimizer's fp32 arithmetic either; looked at every eighth step) or
 // after kmax steps; what is left of the skipped steps only decays m, v (and, for AdamW, w) and is applied in closed
 // form.
 #include "rowstate_body.h"

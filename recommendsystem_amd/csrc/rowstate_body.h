@@ -96,7 +96,9 @@ __device__ __forceinline__ void replay_zero_grad_steps(const ReplayConsts& c, fl
                 const float term = ss * m[e] * __builtin_amdgcn_rcpf(den);
                 if (adamw) w[e] *= decay;
                 w[e] -= term;
-                live |= fabsf(term) > 7.5e-9f * fabsf(w[e]);
+                // (below 2^-25 |w| -- less than half an ulp of w -- the subtraction leaves w as it is, in the dense
+                //  optimizer's fp32 arithmetic as well, and the terms only get smaller from step to step)
+                live |= fabsf(term) > 2.9e-8f * fabsf(w[e]);
             }
             return live;
         };
