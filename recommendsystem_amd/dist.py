@@ -116,9 +116,10 @@ def prepare_process_env():
     """Environment a process should have BEFORE it creates its process groups when collectives are going to be captured
     in HIP graphs (DistributedTrainer(use_graph=True)): torch's NCCL process groups then take a fresh event for every
     collective instead of one from their per-device pool.  The watchdog thread of a process group aborts the process
-    when it queries an event "last recorded in a capturing stream" (hipErrorCapturedEvent); that abort was seen once in
-    several hundred captures, with several trainers built one after the other in one process, and an event that a
-    captured collective recorded and returned to the pool is the suspected way for the watchdog to meet one."""
+    when it queries an event "last recorded in a capturing stream" (hipErrorCapturedEvent).  That abort was seen twice
+    in about eighty test processes that build six trainers one after the other and capture some fifteen graphs each --
+    the second time with the pool off, so a pooled event that a captured collective recorded is at most one of the ways
+    for the watchdog to meet such an event; the setting stays because it removes that one."""
     import os
     os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
