@@ -274,8 +274,6 @@ def main():
     if args.launch_check and world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # collectives captured in HIP graphs: see recommendsystem_amd.dist.prepare_process_env
-        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
         launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
@@ -292,6 +290,8 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
+        from recommendsystem_amd.dist import prepare_process_env
+        prepare_process_env()                # collectives are going to be captured in HIP graphs
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
