@@ -119,14 +119,12 @@ def prepare_process_env():
     when it queries an event "last recorded in a capturing stream" (hipErrorCapturedEvent).  That abort was seen twice
     in about eighty test processes that build six trainers one after the other and capture some fifteen graphs each --
     the second time with the pool off, so a pooled event that a captured collective recorded is at most one of the ways
-    for the watchdog to meet such an event; the setting stays because it removes that one.  The query is harmless for
-    the step (the collectives it concerns are finished or belong to a graph), so the watchdog is also told not to take
-    the process down when it fails (it logs the error and ends; a heartbeat monitor that would then miss it is turned
-    off with it).  Every variable is only set when the caller's environment does not name it."""
+    for the watchdog to meet such an event; the setting stays because it removes that one.  (Telling the watchdog not to
+    rethrow -- TORCH_NCCL_RETHROW_CUDA_ERRORS=0 with the heartbeat monitor off -- was tried: the thread then ends quietly
+    and the process hangs the next time something waits for it, which is worse than the abort.)  The variable is only
+    set when the caller's environment does not name it."""
     import os
     os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
-    os.environ.setdefault("TORCH_NCCL_RETHROW_CUDA_ERRORS", "0")
-    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
 
 
 class Comm:
