@@ -290,8 +290,6 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
-        from recommendsystem_amd.dist import prepare_process_env
-        prepare_process_env()                # collectives are going to be captured in HIP graphs
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:

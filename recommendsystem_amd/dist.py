@@ -112,21 +112,6 @@ class BucketLayout:
 # -------------------------------------------------------------------------------------------------
 # collectives
 # -------------------------------------------------------------------------------------------------
-def prepare_process_env():
-    """Environment a process should have BEFORE it creates its process groups when collectives are going to be captured
-    in HIP graphs (DistributedTrainer(use_graph=True)): torch's NCCL process groups then take a fresh event for every
-    collective instead of one from their per-device pool.  The watchdog thread of a process group aborts the process
-    when it queries an event "last recorded in a capturing stream" (hipErrorCapturedEvent).  That abort was seen twice
-    in about eighty test processes that build six trainers one after the other and capture some fifteen graphs each --
-    the second time with the pool off, so a pooled event that a captured collective recorded is at most one of the ways
-    for the watchdog to meet such an event; the setting stays because it removes that one.  (Telling the watchdog not to
-    rethrow -- TORCH_NCCL_RETHROW_CUDA_ERRORS=0 with the heartbeat monitor off -- was tried: the thread then ends quietly
-    and the process hangs the next time something waits for it, which is worse than the abort.)  The variable is only
-    set when the caller's environment does not name it."""
-    import os
-    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
-
-
 class Comm:
     """torch.distributed wrapper.  stage_cpu=True moves tensors through host memory around each
     collective (for the gloo backend, which is what the CPU tests and single-GPU rehearsals use).

@@ -287,8 +287,6 @@ if __name__ == "__main__":
     mode, outdir = sys.argv[1], sys.argv[2]
     if mode == "gpu1":
         torch.cuda.set_device(0)
-        from recommendsystem_amd.dist import prepare_process_env
-        prepare_process_env()                                          # as bench.py does
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
