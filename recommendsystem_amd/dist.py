@@ -471,6 +471,15 @@ class ShardedExchange:
                           "raise bucket_slack")
 
 
+def _settle_collectives():
+    """The warm-up steps of a capture issue their collectives for real; the process group's watchdog polls the events of
+    those every 100 ms until they are done, and must be through with them before the streams they ran on start
+    capturing."""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.3)
+
+
 def _capture_with_collectives(trainer, idx, labels, next_idx=None, entry=None, run_prologue=False):
     """FusedTrainer._capture for a step with RCCL collectives inside.  The warm-up steps (and the first replay) run for
     real -- collectives included, on every rank -- and are undone.  Other threads of the process group (its watchdog)
@@ -673,6 +682,9 @@ class DistributedTrainer(FusedTrainer):
     # ---- the whole step as one HIP graph, collectives inside --------------------------------------------
     def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
         return _capture_with_collectives(self, idx, labels, next_idx, entry, run_prologue)
+
+    def _before_capture(self):
+        _settle_collectives()
 
     def step_tensors(self, idx, labels, resident: bool = False, next_idx=None):
         """FusedTrainer.step_tensors.  With use_graph, an announced next batch gets a HIP graph of its own for its key
@@ -891,6 +903,9 @@ class ReplicatedTablesTrainer(FusedTrainer):
 
     def _capture(self, idx, labels, next_idx=None, entry=None, run_prologue=False):
         return _capture_with_collectives(self, idx, labels)
+
+    def _before_capture(self):
+        _settle_collectives()
 
     def sync_to_model(self):
         """Nothing to gather: the model's tables are this rank's replica (rows left behind are brought up to date)."""

@@ -1029,6 +1029,7 @@ class FusedTrainer:
         for t, c in snap:
             t.copy_(c)
         self._ahead = dict(entry) if entry else None
+        self._before_capture()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=self._capture_error_mode), \
                 ops.use_workspace(self.ws):
@@ -1044,6 +1045,9 @@ class FusedTrainer:
         self._ahead = dict(entry) if entry else None
         ent["graph"] = g
         return ent
+
+    def _before_capture(self):
+        """Between the warm-up steps and the capture (trainers whose warm-up steps issue collectives wait here)."""
 
     def _mutable_state(self):
         ts = [self.flat_w, self.step_count, self.hyper, self.scal]
